@@ -1,0 +1,166 @@
+/*
+ * pointrcnn_hip.h -- C ABI of libpointrcnn_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the PointRCNN point-cloud hot path: the native launcher
+ * functions that the reference's TF custom-op shims call (tf_sampling.cpp,
+ * tf_grouping.cpp, tf_interpolate.cpp) and the rotated NMS of utils/nms_rotate.py.
+ * Each entry point cites the reference interface it replaces (file:line relative to
+ * the reference tree).  Parameter lists are the reference launchers' parameter lists
+ * plus a trailing stream and an int status return.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'd or torch-ROCm storage) unless
+ *     named host_*; tensors are dense row-major fp32 / int32 as in the reference.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All work
+ *     is enqueued asynchronously on it; no entry point synchronises the device,
+ *     allocates or frees memory, or keeps state between calls.
+ *   - the caller owns every buffer including workspaces (as TF's allocate_output /
+ *     allocate_temp did, tf_sampling.cpp:108-117); *_workspace_bytes() size them.
+ *   - return value: PRCNN_OK or a negative prcnn_status; nothing throws.  The shape /
+ *     attribute checks mirror the reference's OP_REQUIRES list (tf_sampling.cpp:99,105;
+ *     tf_grouping.cpp:71,74,79,84; tf_interpolate.cpp:163,168,203,206).
+ *   - re-entrant and thread-safe: kernels are stateless.
+ */
+#ifndef POINTRCNN_HIP_H
+#define POINTRCNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *prcnn_stream_t; /* hipStream_t */
+
+typedef enum {
+    PRCNN_OK = 0,
+    PRCNN_BAD_ARG = -1,      /* non-positive attr: npoint, radius, nsample, ...      */
+    PRCNN_BAD_SHAPE = -2,    /* negative / inconsistent dimension, NULL tensor       */
+    PRCNN_HIP_ERROR = -3,    /* a HIP runtime call or kernel launch failed           */
+    PRCNN_WORKSPACE = -4,    /* workspace missing or smaller than *_workspace_bytes  */
+    PRCNN_UNSUPPORTED = -5   /* size beyond what the kernels are built for           */
+} prcnn_status;
+
+const char *prcnn_status_string(int status);
+int prcnn_version(void);
+
+/* ---- sampling ---------------------------------------------------------------------- */
+
+/* farthestpointsamplingLauncher(int b,int n,int m,const float* inp,float* temp,int* out)
+ *   tf_sampling.cpp:94, tf_sampling_g.cu:105-170,203-205.
+ * inp (b,n,3) -> out (b,m) int32.  out[:,0]=0; m-1 greedy iterations with the
+ * reference's fp32 distance (no FMA contraction) and tie-break (max value, then
+ * smallest k mod 512, then smallest k).  `temp` is the reference's scratch argument
+ * (32*n floats there): here it is only touched when n > 32768 (clouds too large for
+ * one CU's registers + LDS) and must then hold prcnn_fps_temp_bytes(b,n) bytes; it
+ * may be NULL otherwise. */
+int prcnn_farthest_point_sample(int b, int n, int m, const float *inp, float *temp,
+                                int *out, prcnn_stream_t stream);
+size_t prcnn_fps_temp_bytes(int b, int n);
+
+/* gatherpointLauncher(int b,int n,int m,const float* inp,const int* idx,float* out)
+ *   tf_sampling.cpp:125, tf_sampling_g.cu:172-181.  out[b,j,:] = inp[b,idx[b,j],:], C=3 */
+int prcnn_gather_point(int b, int n, int m, const float *inp, const int *idx, float *out,
+                       prcnn_stream_t stream);
+
+/* ---- grouping ---------------------------------------------------------------------- */
+
+/* queryBallPointLauncher(int b,int n,int m,float radius,int nsample,const float* xyz1,
+ *                        const float* xyz2,int* idx,int* pts_cnt)
+ *   tf_grouping.cpp:66, tf_grouping_g.cu:3-36,125-128.
+ * xyz1 (b,n,3) points, xyz2 (b,m,3) centroids -> idx (b,m,nsample), pts_cnt (b,m).
+ * First `nsample` points in INDEX ORDER with max(sqrtf(d2),1e-20f) < radius; rows are
+ * padded with the first hit; rows without any hit are left unwritten (as the
+ * reference leaves them) and get pts_cnt 0.  pts_cnt may be NULL. */
+int prcnn_query_ball_point(int b, int n, int m, float radius, int nsample,
+                           const float *xyz1, const float *xyz2, int *idx, int *pts_cnt,
+                           prcnn_stream_t stream);
+
+/* groupPointLauncher(int b,int n,int c,int m,int nsample,const float* points,
+ *                    const int* idx,float* out)   tf_grouping.cpp:142, tf_grouping_g.cu:40-57
+ * out[b,j,k,:] = points[b,idx[b,j,k],:]  -> (b,m,nsample,c) */
+int prcnn_group_point(int b, int n, int c, int m, int nsample, const float *points,
+                      const int *idx, float *out, prcnn_stream_t stream);
+
+/* ---- 3d_interpolation -------------------------------------------------------------- */
+
+/* threenn_cpu(int b,int n,int m,const float* xyz1,const float* xyz2,float* dist,int* idx)
+ *   tf_interpolate.cpp:60-103.  For each of the n points of xyz1 the 3 nearest of the m
+ * points of xyz2: SQUARED fp32 distances ascending + indices; ties keep the earlier
+ * index; with m<3 the missing slots are (+inf, 0). */
+int prcnn_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist,
+                   int *idx, prcnn_stream_t stream);
+
+/* threeinterpolate_cpu(int b,int m,int c,int n,const float* points,const int* idx,
+ *                      const float* weight,float* out)    tf_interpolate.cpp:107-127
+ * NOTE the (b, m, c, n) order.  out[b,j,:] = p[i1]*w1 + p[i2]*w2 + p[i3]*w3, evaluated
+ * left to right without FMA contraction (bit-exact with the CPU reference). */
+int prcnn_three_interpolate(int b, int m, int c, int n, const float *points, const int *idx,
+                            const float *weight, float *out, prcnn_stream_t stream);
+
+/* Inverse-distance weights of pointnet_fp_module, models/pointnet_util.py:211-214:
+ *   dist=max(dist,1e-10); norm=sum(1/dist); weight=(1/dist)/norm      rows = b*n */
+int prcnn_fp_weights(int64_t rows, const float *dist, float *weight, prcnn_stream_t stream);
+
+/* Fused three_nn + weights + three_interpolate (pointnet_util.py:210-215 in one launch;
+ * additive, the three primitives above stay available).  xyz1 (b,n,3), xyz2 (b,m,3),
+ * points2 (b,m,c) -> out rows of c floats written at out + row*ldo (ldo >= c lets the
+ * caller write straight into the left part of the FP concat buffer,
+ * pointnet_util.py:218).  dist / idx (b,n,3) are optional outputs (may be NULL). */
+int prcnn_three_nn_interpolate(int b, int n, int m, int c, const float *xyz1,
+                               const float *xyz2, const float *points2, float *out,
+                               int64_t ldo, float *dist, int *idx, prcnn_stream_t stream);
+
+/* ---- rotated BEV NMS --------------------------------------------------------------- */
+
+/* nms_rotate_cpu(boxes, scores, iou_threshold, max_output_size)  utils/nms_rotate.py:39-73
+ * boxes (n,5) float64 [x_c, y_c, w, h, theta_deg] exactly as the reference callers build
+ * them (dataset/frustum_dataset.py:126-128), scores (n,) float64.  Greedy NMS in
+ * descending score order (ties: lower index first), rectangles as OpenCV RotatedRect
+ * ((b1,b0),(b3,b2),b4), iou = I/(a1+a2-I+1e-7), suppress when iou >= threshold, stop at
+ * max_output_size.  keep receives up to min(n,max_output_size) int64 indices into the
+ * ORIGINAL arrays, score-descending; *n_keep (device int) the count.  All arithmetic is
+ * float64 on the device.  workspace: prcnn_nms_rotate_workspace_bytes(n) bytes. */
+size_t prcnn_nms_rotate_workspace_bytes(int n);
+int prcnn_nms_rotate(int n, const double *boxes, const double *scores, double iou_threshold,
+                     int max_output_size, int64_t *keep, int *n_keep, void *workspace,
+                     size_t workspace_bytes, prcnn_stream_t stream);
+
+/* ---- shared MLP (1x1 conv + folded BN + ReLU) and pooling --------------------------- */
+
+/* One shared-MLP layer, models/tf_util.py:120-185 (conv2d 1x1 + bias + batch_norm +
+ * ReLU) with the inference-time BN folded by the caller into scale/shift:
+ *   out[r, o] = act( scale[o] * sum_k x[r,k] * w[k,o] + shift[o] )
+ * x rows at x + r*ldx (cin floats), w (cin,cout) row-major, out rows at out + r*ldo.
+ * If pool > 1, consecutive groups of `pool` rows are max-reduced on the fly
+ * (pointnet_util.py:126,192) and out has rows/pool rows.  precision: 0 = fp32 MFMA
+ * (exact fp32 FMA chain), 1 = bf16 MFMA with fp32 accumulation. */
+int prcnn_mlp_layer(int64_t rows, int cin, int cout, const float *x, int64_t ldx,
+                    const float *w, const float *scale, const float *shift, int relu,
+                    int pool, int precision, float *out, int64_t ldo, prcnn_stream_t stream);
+
+/* First layer of a set-abstraction scale fused with the grouping
+ * (pointnet_util.py:177-190 / :43-53 in one launch): the (b,m,nsample,C+3) grouped
+ * tensor is never materialised.  Row (b,j,k) of the implicit input is
+ *   xyz_first == 0 (MSG, :183): [ feats[b,idx,:] , xyz[b,idx,:]-new_xyz[b,j,:] ]
+ *   xyz_first == 1 (SSG, :49):  [ xyz[b,idx,:]-new_xyz[b,j,:] , feats[b,idx,:] ]
+ * feats may be NULL (c=0: points=None, :52/:185).  Followed by the same epilogue as
+ * prcnn_mlp_layer (w is (c+3, cout)). */
+int prcnn_sa_group_mlp_layer(int b, int n, int m, int nsample, int c, const float *xyz,
+                             const float *feats, const float *new_xyz, const int *idx,
+                             int xyz_first, int cout, const float *w, const float *scale,
+                             const float *shift, int relu, int pool, int precision,
+                             float *out, int64_t ldo, prcnn_stream_t stream);
+
+/* Max over consecutive groups of `nsample` rows, models/pointnet_util.py:126,192
+ * (tf.reduce_max over the nsample axis) for group sizes the fused epilogue of
+ * prcnn_mlp_layer does not cover (pool must there be 16, 32, 64 or 128).
+ * x rows at x + r*ldx (c floats), out (groups, c) rows at out + g*ldo. */
+int prcnn_max_pool(int64_t groups, int nsample, int c, const float *x, int64_t ldx, float *out,
+                   int64_t ldo, prcnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POINTRCNN_HIP_H */

@@ -1,0 +1,67 @@
+"""ctypes binding of libpointrcnn_hip.so (the C ABI declared in include/pointrcnn_hip.h).
+
+The library is the product: there is NO CPU or eager-PyTorch fallback.  If the shared
+object is missing, `lib()` raises and every op fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpointrcnn_hip.so")
+
+_c = ctypes
+_vp, _i, _f, _d, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_double, _c.c_int64, _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/pointrcnn_hip.h one to one
+SIGNATURES = {
+    "prcnn_status_string": (_c.c_char_p, [_i]),
+    "prcnn_version": (_i, []),
+    "prcnn_farthest_point_sample": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "prcnn_fps_temp_bytes": (_sz, [_i, _i]),
+    "prcnn_gather_point": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "prcnn_query_ball_point": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "prcnn_group_point": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "prcnn_three_nn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "prcnn_three_interpolate": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "prcnn_fp_weights": (_i, [_i64, _vp, _vp, _vp]),
+    "prcnn_three_nn_interpolate": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "prcnn_nms_rotate_workspace_bytes": (_sz, [_i]),
+    "prcnn_nms_rotate": (_i, [_i, _vp, _vp, _d, _i, _vp, _vp, _vp, _sz, _vp]),
+    "prcnn_mlp_layer": (_i, [_i64, _i, _i, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp]),
+    "prcnn_sa_group_mlp_layer": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp,
+                                      _i, _i, _i, _vp, _i64, _vp]),
+    "prcnn_max_pool": (_i, [_i64, _i, _i, _vp, _i64, _vp, _i64, _vp]),
+}
+
+_lib = None
+
+
+class PointRCNNHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared library once; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PointRCNNHipError(
+                "libpointrcnn_hip.so not found at %s -- build it with "
+                "`python -m pointrcnn_amd.build` (there is no fallback path)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)       # AttributeError if the ABI and the header disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    """Map the C status to the exception the reference's OP_REQUIRES would raise."""
+    if status == 0:
+        return
+    msg = lib().prcnn_status_string(status).decode()
+    if status in (-1, -2):
+        raise ValueError("%s: %s" % (what, msg))
+    raise PointRCNNHipError("%s: %s" % (what, msg))

@@ -1,0 +1,54 @@
+// Shared helpers for the gfx950 kernels of libpointrcnn_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pointrcnn_hip.h"
+
+#define PRCNN_LAUNCH_CHECK()                                   \
+    do {                                                       \
+        if (hipGetLastError() != hipSuccess) return PRCNN_HIP_ERROR; \
+    } while (0)
+
+static inline hipStream_t to_stream(prcnn_stream_t s) { return (hipStream_t)s; }
+
+namespace prcnn {
+
+// ---- DPP cross-lane moves (wave64; rows of 16 lanes) -----------------------------------
+// dpp_ctrl encodings (gfx9): quad_perm = 0x00-0xFF, row_shr:n = 0x110+n, row_mirror = 0x140,
+// row_half_mirror = 0x141, row_bcast:15 = 0x142, row_bcast:31 = 0x143.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_i32(int old, int v)
+{
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
+}
+
+// all-reduce inside each row of 16 lanes: xor1, xor2 (quad_perm), half-mirror, mirror
+__device__ __forceinline__ int row16_allmax_i32(int v)
+{
+    v = max(v, dpp_i32<0xB1>(v, v));   // quad_perm [1,0,3,2]
+    v = max(v, dpp_i32<0x4E>(v, v));   // quad_perm [2,3,0,1]
+    v = max(v, dpp_i32<0x141>(v, v));  // row_half_mirror
+    v = max(v, dpp_i32<0x140>(v, v));  // row_mirror
+    return v;
+}
+__device__ __forceinline__ unsigned row16_allmin_u32(unsigned v)
+{
+    v = min(v, (unsigned)dpp_i32<0xB1>((int)v, (int)v));
+    v = min(v, (unsigned)dpp_i32<0x4E>((int)v, (int)v));
+    v = min(v, (unsigned)dpp_i32<0x141>((int)v, (int)v));
+    v = min(v, (unsigned)dpp_i32<0x140>((int)v, (int)v));
+    return v;
+}
+// wave-wide max of a signed int; result is wave-uniform (SGPR)
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    v = row16_allmax_i32(v);
+    v = max(v, dpp_i32<0x142, 0xA>(v, v));  // row_bcast:15 into rows 1,3
+    v = max(v, dpp_i32<0x143, 0xC>(v, v));  // row_bcast:31 into rows 2,3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+__device__ __forceinline__ int f2i(float f) { return __builtin_bit_cast(int, f); }
+__device__ __forceinline__ float i2f(int i) { return __builtin_bit_cast(float, i); }
+
+}  // namespace prcnn

@@ -1,0 +1,433 @@
+// Shared MLP (1x1 conv + folded BN + ReLU) with optional fused grouping prologue and
+// fused max-pool epilogue, on the gfx950 matrix cores.
+//
+// Replaces the conv2d/batch_norm/relu/reduce_max chain of the reference's
+// pointnet_sa_module[_msg] / pointnet_fp_module (models/pointnet_util.py:116-126,187-192,
+// 222-226; models/tf_util.py:120-185,512-531), which runs cuDNN 1x1 convolutions over a
+// materialised (b,m,nsample,C) tensor.  Here:
+//   * precision 0: v_mfma_f32_32x32x2_f32 -- exact fp32 FMA chain (1e-5 tier);
+//     precision 1: v_mfma_f32_32x32x16_bf16 with fp32 accumulation (1e-2 tier).
+//   * the A operand (rows x K) is either a dense row-major matrix or is formed on the
+//     fly from (xyz, feats, new_xyz, idx): the grouped tensor of group_point never
+//     touches HBM (GATHER prologue);
+//   * the epilogue applies scale/shift/ReLU and, if pool > 1, max-reduces consecutive
+//     groups of `pool` rows before anything is stored (POOL epilogue).
+// Workgroup = 256 threads = 4 waves; block tile 128 x BN (BN = 32, 64 or 128), K in
+// chunks of 16 (fp32) / 32 (bf16) staged through LDS with register prefetch of the next
+// chunk.  Inside a chunk the physical k of MFMA step s / lane-half h is h*8+s, so a
+// lane's A operands of a whole chunk are 8 contiguous floats (2 x ds_read_b128);
+// A rows are padded to 20 floats (conflict-free b128 reads), B is [k][BN] (conflict-free
+// b32 reads).
+#include "common.h"
+
+namespace prcnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+struct MlpArgs {
+    long long rows;
+    int cin, cout;
+    const float *x;
+    long long ldx;
+    const float *w, *scale, *shift;
+    int relu, pool;
+    float *out;
+    long long ldo;
+    // gather prologue
+    int n, m, ns, c, xyz_first;
+    const float *xyz, *feats, *new_xyz;
+    const int *idx;
+};
+
+constexpr int MLP_THREADS = 256;
+constexpr int BM = 128;
+
+// ---- A-operand element sources ---------------------------------------------------------
+struct RowSrc {
+    bool valid;
+    long long pi;    // dense: row index; gather: global point index bi*n + idx
+    long long ci;    // gather: centroid index (row / ns)
+};
+
+template <bool GATHER>
+__device__ __forceinline__ RowSrc make_row(const MlpArgs &a, long long r)
+{
+    RowSrc s;
+    s.valid = r < a.rows;
+    s.pi = 0; s.ci = 0;
+    if (s.valid) {
+        if (GATHER) {
+            const long long bi = r / ((long long)a.m * a.ns);
+            s.pi = bi * a.n + a.idx[r];
+            s.ci = r / a.ns;
+        } else {
+            s.pi = r;
+        }
+    }
+    return s;
+}
+
+template <bool GATHER>
+__device__ __forceinline__ float load_a1(const MlpArgs &a, const RowSrc &s, int col)
+{
+    if (!s.valid || col >= a.cin) return 0.f;
+    if (!GATHER) return a.x[s.pi * a.ldx + col];
+    int fc, xc;           // feature column / xyz column (one of them valid)
+    if (a.xyz_first) { xc = col; fc = col - 3; } else { fc = col; xc = col - a.c; }
+    if (fc >= 0 && fc < a.c) return a.feats[s.pi * a.c + fc];
+    return a.xyz[s.pi * 3 + xc] - a.new_xyz[s.ci * 3 + xc];
+}
+
+// 4 consecutive columns starting at col (col % 4 == 0)
+template <bool GATHER>
+__device__ __forceinline__ f32x4 load_a4(const MlpArgs &a, const RowSrc &s, int col, bool vec_ok)
+{
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!s.valid || col >= a.cin) return v;
+    if (!GATHER) {
+        if (vec_ok && col + 4 <= a.cin) return *reinterpret_cast<const f32x4 *>(a.x + s.pi * a.ldx + col);
+    } else {
+        if (vec_ok && !a.xyz_first && col + 4 <= a.c)
+            return *reinterpret_cast<const f32x4 *>(a.feats + s.pi * a.c + col);
+    }
+    v[0] = load_a1<GATHER>(a, s, col);
+    v[1] = load_a1<GATHER>(a, s, col + 1);
+    v[2] = load_a1<GATHER>(a, s, col + 2);
+    v[3] = load_a1<GATHER>(a, s, col + 3);
+    return v;
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
+{
+    // round-to-nearest-even via the hardware conversion (keeps NaN a NaN)
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 f = {lo, hi};
+    bf2 b = __builtin_convertvector(f, bf2);
+    return __builtin_bit_cast(unsigned, b);
+}
+
+// ---- kernel ---------------------------------------------------------------------------
+// WM x WN waves (WM*WN == 4), each wave owns TM x TN MFMA tiles of 32x32.
+template <int WM, int WN, int TM, int TN, bool GATHER, bool BF16>
+__global__ __launch_bounds__(MLP_THREADS) void mlp_kernel(const MlpArgs a)
+{
+    constexpr int BN = WN * TN * 32;
+    constexpr int BK = BF16 ? 32 : 16;
+    // LDS row strides (in 4-byte words): fp32 A rows 16 -> 20; bf16 A rows 32 bf16 = 16 words -> 20
+    constexpr int AS = 20;
+    constexpr int A_WORDS = BM * AS;
+    // B: fp32 [BK][BN] words; bf16 transposed [BN][BK] bf16 = [BN][16 words] -> stride 20
+    constexpr int B_WORDS = BF16 ? BN * AS : BK * BN;
+    constexpr int POOL_WORDS = (BM / 16) * BN;
+    constexpr int LDS_WORDS = (A_WORDS + B_WORDS) > POOL_WORDS ? (A_WORDS + B_WORDS) : POOL_WORDS;
+    __shared__ __attribute__((aligned(16))) unsigned lds[LDS_WORDS];
+    unsigned *As = lds;
+    unsigned *Bs = lds + A_WORDS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, kh = lane >> 5;
+    const long long row0 = (long long)blockIdx.x * BM;
+    const int col0 = blockIdx.y * BN;
+
+    // ---- staging assignment -------------------------------------------------------------
+    // A: BM x BK elements; thread -> (row = tid/2, half = tid&1): BK/2 consecutive k
+    constexpr int A_PER = BK / 2;                    // 8 (fp32) or 16 (bf16) elements
+    const int arow = tid >> 1, ahalf = tid & 1;
+    const RowSrc rs = make_row<GATHER>(a, row0 + arow);
+    const bool a_vec = GATHER ? ((a.c & 3) == 0 && (((uintptr_t)a.feats) & 15) == 0)
+                              : ((a.ldx & 3) == 0 && (((uintptr_t)a.x) & 15) == 0);
+    // B: BK x BN elements; thread -> k = tid / (BN/BPT), n-offset
+    constexpr int B_PER = BK * BN / MLP_THREADS;     // elements per thread
+    constexpr int B_TPR = BN / B_PER;                // threads per k-row
+    const int bk = tid / B_TPR, bn = (tid % B_TPR) * B_PER;
+    const bool b_vec = (a.cout & 3) == 0 && (((uintptr_t)a.w) & 15) == 0;
+
+    f32x4 areg[A_PER / 4];
+    f32x4 breg[(B_PER + 3) / 4];
+
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int v = 0; v < A_PER / 4; ++v)
+            areg[v] = load_a4<GATHER>(a, rs, k0 + ahalf * A_PER + v * 4, a_vec);
+        const int k = k0 + bk;
+#pragma unroll
+        for (int v = 0; v < (B_PER + 3) / 4; ++v) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            const int n = col0 + bn + v * 4;
+            if (k < a.cin) {
+                const float *wp = a.w + (size_t)k * a.cout + n;
+                if (b_vec && B_PER >= 4 && n + 4 <= a.cout) t = *reinterpret_cast<const f32x4 *>(wp);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (n + e < a.cout && v * 4 + e < B_PER) t[e] = wp[e];
+                }
+            }
+            breg[v] = t;
+        }
+    };
+    auto store_chunk = [&]() {
+        if (!BF16) {
+#pragma unroll
+            for (int v = 0; v < A_PER / 4; ++v)
+                *reinterpret_cast<f32x4 *>(&As[arow * AS + ahalf * A_PER + v * 4]) = areg[v];
+#pragma unroll
+            for (int v = 0; v < (B_PER + 3) / 4; ++v) {
+                if (B_PER >= 4) *reinterpret_cast<f32x4 *>(&Bs[bk * BN + bn + v * 4]) = breg[v];
+                else {
+#pragma unroll
+                    for (int e = 0; e < B_PER; ++e) Bs[bk * BN + bn + e] = __builtin_bit_cast(unsigned, breg[v][e]);
+                }
+            }
+        } else {
+            // A: 16 bf16 per thread = 8 words at As[arow][ahalf*8 ..]
+#pragma unroll
+            for (int v = 0; v < A_PER / 4; ++v) {
+                As[arow * AS + ahalf * 8 + v * 2 + 0] = pack_bf16x2(areg[v][0], areg[v][1]);
+                As[arow * AS + ahalf * 8 + v * 2 + 1] = pack_bf16x2(areg[v][2], areg[v][3]);
+            }
+            // B transposed: element (k=bk, n) -> half-word bk of row n
+            unsigned short *Bh = reinterpret_cast<unsigned short *>(Bs);
+#pragma unroll
+            for (int v = 0; v < (B_PER + 3) / 4; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v * 4 + e < B_PER)
+                        Bh[(bn + v * 4 + e) * (AS * 2) + bk] =
+                            (unsigned short)(pack_bf16x2(breg[v][e], 0.f) & 0xffffu);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = (a.cin + BK - 1) / BK;
+    load_chunk(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();                 // previous chunk's reads are done
+        store_chunk();
+        __syncthreads();
+        if (ch + 1 < nchunks) load_chunk((ch + 1) * BK);
+        if (!BF16) {
+            f32x4 af[TM][2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const unsigned *p = &As[((wm * TM + i) * 32 + li) * AS + kh * 8];
+                af[i][0] = *reinterpret_cast<const f32x4 *>(p);
+                af[i][1] = *reinterpret_cast<const f32x4 *>(p + 4);
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                float bf[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bf[j] = __builtin_bit_cast(float, Bs[(kh * 8 + s) * BN + (wn * TN + j) * 32 + li]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s >> 2][s & 3], bf[j],
+                                                                         acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // two k-steps of 16: lane (li, kh) holds k = 16*s + 8*kh + 0..7
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 af[TM], bfr[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8 *>(
+                        &As[((wm * TM + i) * 32 + li) * AS + s * 8 + kh * 4]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bfr[j] = *reinterpret_cast<const bf16x8 *>(
+                        &Bs[((wn * TN + j) * 32 + li) * AS + s * 8 + kh * 4]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: scale/shift/relu, then store or pool -----------------------------------
+    // C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float sc[TN], sh[TN];
+    bool cok[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + (wn * TN + j) * 32 + li;
+        cok[j] = col < a.cout;
+        sc[j] = cok[j] ? a.scale[col] : 0.f;
+        sh[j] = cok[j] ? a.shift[col] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r] * sc[j] + sh[j];
+                if (a.relu) v = fmaxf(v, 0.f);
+                acc[i][j][r] = v;
+            }
+
+    if (a.pool <= 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = col0 + (wn * TN + j) * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long row = row0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (cok[j] && row < a.rows) a.out[row * a.ldo + col] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+    // pooled: 16-row granule maxima -> LDS -> combine pool/16 granules.
+    // rows >= a.rows cannot occur inside a group (rows % pool == 0, BM % pool == 0).
+    __syncthreads();                     // staging LDS is dead from here
+    float *Ps = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {        // regs 8g..8g+7 = rows 16g..16g+15 of the tile
+                float mx = acc[i][j][8 * g];
+#pragma unroll
+                for (int r = 1; r < 8; ++r) mx = fmaxf(mx, acc[i][j][8 * g + r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                if (kh == 0) Ps[(((wm * TM + i) * 2) + g) * BN + (wn * TN + j) * 32 + li] = mx;
+            }
+    __syncthreads();
+    const int gpp = a.pool / 16;                  // granules per pooled group
+    const int groups = BM / a.pool;
+    for (int e = tid; e < groups * BN; e += MLP_THREADS) {
+        const int g = e / BN, cl = e - g * BN;
+        const int col = col0 + cl;
+        const long long orow = row0 / a.pool + g;
+        if (col < a.cout && orow * a.pool < a.rows) {
+            float mx = Ps[(g * gpp) * BN + cl];
+            for (int q = 1; q < gpp; ++q) mx = fmaxf(mx, Ps[(g * gpp + q) * BN + cl]);
+            a.out[orow * a.ldo + col] = mx;
+        }
+    }
+}
+
+// standalone max-pool over consecutive groups of rows (pool sizes the fused epilogue
+// does not cover): x (groups*ns, c) -> out (groups, c)
+__global__ void max_pool_kernel(long long groups, int ns, int c, const float *__restrict__ x,
+                                long long ldx, float *__restrict__ out, long long ldo)
+{
+    const long long total = groups * c;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const long long g = e / c;
+        const int l = (int)(e - g * c);
+        float mx = x[(g * ns) * ldx + l];
+        for (int k = 1; k < ns; ++k) mx = fmaxf(mx, x[(g * ns + k) * ldx + l]);
+        out[g * ldo + l] = mx;
+    }
+}
+
+template <bool GATHER, bool BF16>
+static int launch_mlp(const MlpArgs &a, hipStream_t st)
+{
+    const long long rb = (a.rows + BM - 1) / BM;
+    if (rb > 0x7fffffffLL) return PRCNN_UNSUPPORTED;
+    if (a.cout <= 32) {
+        dim3 grid((unsigned)rb, (a.cout + 31) / 32);
+        hipLaunchKernelGGL((mlp_kernel<4, 1, 1, 1, GATHER, BF16>), grid, dim3(MLP_THREADS), 0, st, a);
+    } else if (a.cout <= 64) {
+        dim3 grid((unsigned)rb, (a.cout + 63) / 64);
+        hipLaunchKernelGGL((mlp_kernel<4, 1, 1, 2, GATHER, BF16>), grid, dim3(MLP_THREADS), 0, st, a);
+    } else {
+        dim3 grid((unsigned)rb, (a.cout + 127) / 128);
+        hipLaunchKernelGGL((mlp_kernel<2, 2, 2, 2, GATHER, BF16>), grid, dim3(MLP_THREADS), 0, st, a);
+    }
+    PRCNN_LAUNCH_CHECK();
+    return PRCNN_OK;
+}
+
+static int check_common(long long rows, int cin, int cout, const float *w, const float *scale,
+                        const float *shift, int pool, int precision, const float *out, long long ldo)
+{
+    if (rows < 0 || cin <= 0 || cout <= 0) return PRCNN_BAD_SHAPE;
+    if (!w || !scale || !shift || !out) return PRCNN_BAD_SHAPE;
+    if (precision != 0 && precision != 1) return PRCNN_BAD_ARG;
+    if (pool < 1) return PRCNN_BAD_ARG;
+    if (ldo < cout) return PRCNN_BAD_SHAPE;
+    if (pool > 1) {
+        if (pool % 16 != 0 || BM % pool != 0) return PRCNN_UNSUPPORTED;
+        if (rows % pool != 0) return PRCNN_BAD_SHAPE;
+    }
+    return PRCNN_OK;
+}
+
+}  // namespace prcnn
+
+extern "C" int prcnn_mlp_layer(int64_t rows, int cin, int cout, const float *x, int64_t ldx,
+                               const float *w, const float *scale, const float *shift, int relu,
+                               int pool, int precision, float *out, int64_t ldo,
+                               prcnn_stream_t stream)
+{
+    using namespace prcnn;
+    int rc = check_common(rows, cin, cout, w, scale, shift, pool, precision, out, ldo);
+    if (rc != PRCNN_OK) return rc;
+    if (rows == 0) return PRCNN_OK;
+    if (!x || ldx < cin) return PRCNN_BAD_SHAPE;
+    MlpArgs a = {};
+    a.rows = rows; a.cin = cin; a.cout = cout; a.x = x; a.ldx = ldx; a.w = w; a.scale = scale;
+    a.shift = shift; a.relu = relu; a.pool = pool; a.out = out; a.ldo = ldo;
+    return precision ? launch_mlp<false, true>(a, to_stream(stream))
+                     : launch_mlp<false, false>(a, to_stream(stream));
+}
+
+extern "C" int prcnn_sa_group_mlp_layer(int b, int n, int m, int nsample, int c, const float *xyz,
+                                        const float *feats, const float *new_xyz, const int *idx,
+                                        int xyz_first, int cout, const float *w, const float *scale,
+                                        const float *shift, int relu, int pool, int precision,
+                                        float *out, int64_t ldo, prcnn_stream_t stream)
+{
+    using namespace prcnn;
+    if (b < 0 || n <= 0 || m < 0 || nsample <= 0 || c < 0) return PRCNN_BAD_SHAPE;
+    const long long rows = (long long)b * m * nsample;
+    int rc = check_common(rows, c + 3, cout, w, scale, shift, pool, precision, out, ldo);
+    if (rc != PRCNN_OK) return rc;
+    if (rows == 0) return PRCNN_OK;
+    if (!xyz || !new_xyz || !idx || (c > 0 && !feats)) return PRCNN_BAD_SHAPE;
+    MlpArgs a = {};
+    a.rows = rows; a.cin = c + 3; a.cout = cout; a.w = w; a.scale = scale; a.shift = shift;
+    a.relu = relu; a.pool = pool; a.out = out; a.ldo = ldo;
+    a.n = n; a.m = m; a.ns = nsample; a.c = c; a.xyz_first = xyz_first;
+    a.xyz = xyz; a.feats = feats; a.new_xyz = new_xyz; a.idx = idx;
+    return precision ? launch_mlp<true, true>(a, to_stream(stream))
+                     : launch_mlp<true, false>(a, to_stream(stream));
+}
+
+extern "C" int prcnn_max_pool(int64_t groups, int nsample, int c, const float *x, int64_t ldx,
+                              float *out, int64_t ldo, prcnn_stream_t stream)
+{
+    if (groups < 0 || nsample <= 0 || c <= 0 || ldx < c || ldo < c) return PRCNN_BAD_SHAPE;
+    if (groups == 0) return PRCNN_OK;
+    if (!x || !out) return PRCNN_BAD_SHAPE;
+    long long blocks = (groups * c + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(prcnn::max_pool_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       to_stream(stream), (long long)groups, nsample, c, x, (long long)ldx, out,
+                       (long long)ldo);
+    PRCNN_LAUNCH_CHECK();
+    return PRCNN_OK;
+}

@@ -1,0 +1,329 @@
+// Rotated BEV NMS for gfx950 (MI355X).
+//
+// Replaces nms_rotate_cpu of the reference (utils/nms_rotate.py:39-73: a Python double
+// loop around cv2.rotatedRectangleIntersection / convexHull / contourArea).
+// Three launches on the caller's stream, float64 arithmetic throughout (MI355X runs
+// fp64 VALU at half the fp32 rate, and the reference's boxes/scores are float64):
+//   1. rank_kernel     counting sort: rank_i = #{j : s_j > s_i or (s_j == s_i and j < i)}
+//                      (scores tiled through LDS) and the per-box geometry record
+//                      written at its rank -> everything downstream is in score order.
+//   2. mask_kernel     all-pairs suppression bitmask, one wave per 64x64 block of the
+//                      upper triangle.  Each lane first screens its row against the 64
+//                      column boxes with a circumscribed-circle test, the surviving
+//                      (row, col) pairs are compacted across the wave, and only those
+//                      run the exact convex-polygon clip (Sutherland-Hodgman of one
+//                      rectangle against the other in the other's own axis-aligned
+//                      frame).  bit(r,c) = iou >= threshold, c > r.
+//   3. sweep_kernel    one wave walks the ranks serially: next unsuppressed rank ->
+//                      keep, OR its mask row into the LDS-resident `removed` bitmap;
+//                      stops at max_output_size (nms_rotate.py:46-47).
+// Rectangle convention = OpenCV RotatedRect((b1,b0),(b3,b2),b4) (nms_rotate.py:53,60):
+// centre (u,v)=(b1,b0), width W=b3 along (cos t, sin t), height H=b2 along (sin t,-cos t).
+#include "common.h"
+
+namespace prcnn {
+
+struct BoxRec {            // 64 bytes, written at the box's rank
+    double u, v;           // centre
+    double c, s;           // cos / sin of the angle
+    double hw, hh;         // half width (b3/2), half height (b2/2)
+    double area;           // b2*b3 (nms_rotate.py:55)
+    double rad;            // circumscribed radius
+};
+
+constexpr int RANK_THREADS = 256;
+constexpr int RANK_TILE = 2048;
+
+__global__ __launch_bounds__(RANK_THREADS) void rank_kernel(int n, const double *__restrict__ boxes,
+                                                            const double *__restrict__ scores,
+                                                            int *__restrict__ order,
+                                                            BoxRec *__restrict__ rec)
+{
+    __shared__ double ss[RANK_TILE];
+    const int i = blockIdx.x * RANK_THREADS + threadIdx.x;
+    const bool ok = i < n;
+    const double si = ok ? scores[i] : 0.0;
+    int rank = 0;
+    for (int base = 0; base < n; base += RANK_TILE) {
+        const int tn = min(RANK_TILE, n - base);
+        __syncthreads();
+        for (int k = threadIdx.x; k < tn; k += RANK_THREADS) ss[k] = scores[base + k];
+        __syncthreads();
+        if (ok) {
+            for (int k = 0; k < tn; ++k) {
+                const double sj = ss[k];
+                rank += (sj > si || (sj == si && base + k < i)) ? 1 : 0;
+            }
+        }
+    }
+    if (ok) {
+        order[rank] = i;
+        const double *b = boxes + (size_t)i * 5;
+        const double ang = b[4] * 3.14159265358979323846 / 180.0;
+        BoxRec r;
+        r.u = b[1]; r.v = b[0];
+        sincos(ang, &r.s, &r.c);
+        r.hw = 0.5 * b[3]; r.hh = 0.5 * b[2];
+        r.area = b[2] * b[3];
+        r.rad = sqrt(r.hw * r.hw + r.hh * r.hh);
+        rec[rank] = r;
+    }
+}
+
+// Clip polygon (px,py)[0..cnt) against the half-plane  sgn*coord <= lim  where coord is x
+// (axis 0) or y (axis 1).  Sutherland-Hodgman step; at most cnt+1 output vertices.
+__device__ __forceinline__ int clip_axis(const double *px, const double *py, int cnt, int axis,
+                                         double sgn, double lim, double *ox, double *oy)
+{
+    int no = 0;
+    for (int i = 0; i < cnt; ++i) {
+        const int i2 = (i + 1 == cnt) ? 0 : i + 1;
+        const double ax = px[i], ay = py[i], bx = px[i2], by = py[i2];
+        const double da = lim - sgn * (axis == 0 ? ax : ay);   // >= 0 inside
+        const double db = lim - sgn * (axis == 0 ? bx : by);
+        if (da >= 0) { ox[no] = ax; oy[no] = ay; ++no; }
+        if ((da >= 0) != (db >= 0)) {
+            const double t = da / (da - db);
+            ox[no] = ax + t * (bx - ax);
+            oy[no] = ay + t * (by - ay);
+            ++no;
+        }
+    }
+    return no;
+}
+
+// Intersection area of rectangle q with rectangle p, evaluated in p's frame.
+__device__ double rect_intersection(const BoxRec &p, const BoxRec &q)
+{
+    // q's corners (OpenCV RotatedRect::points order) relative to p's centre
+    double gx[4], gy[4];
+    const double wx = q.c * q.hw, wy = q.s * q.hw;      // half width vector
+    const double hx = q.s * q.hh, hy = -q.c * q.hh;     // half height vector
+    const double ox = q.u - p.u, oy = q.v - p.v;
+    gx[0] = ox - wx - hx; gy[0] = oy - wy - hy;
+    gx[1] = ox - wx + hx; gy[1] = oy - wy + hy;
+    gx[2] = ox + wx + hx; gy[2] = oy + wy + hy;
+    gx[3] = ox + wx - hx; gy[3] = oy + wy - hy;
+    double ax[8], ay[8], bx[8], by[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {       // rotate into p's (width, height) axes
+        ax[k] = gx[k] * p.c + gy[k] * p.s;
+        ay[k] = gx[k] * p.s - gy[k] * p.c;
+    }
+    int cnt = 4;
+    cnt = clip_axis(ax, ay, cnt, 0, 1.0, p.hw, bx, by);
+    if (cnt < 3) return 0.0;
+    cnt = clip_axis(bx, by, cnt, 0, -1.0, p.hw, ax, ay);
+    if (cnt < 3) return 0.0;
+    cnt = clip_axis(ax, ay, cnt, 1, 1.0, p.hh, bx, by);
+    if (cnt < 3) return 0.0;
+    cnt = clip_axis(bx, by, cnt, 1, -1.0, p.hh, ax, ay);
+    if (cnt < 3) return 0.0;
+    double s = 0.0;
+    for (int i = 0; i < cnt; ++i) {
+        const int i2 = (i + 1 == cnt) ? 0 : i + 1;
+        s += ax[i] * ay[i2] - ax[i2] * ay[i];
+    }
+    return 0.5 * fabs(s);
+}
+
+// One wave per (row block, col block) of the upper triangle.
+__global__ __launch_bounds__(64) void mask_kernel(int n, int words, double thr,
+                                                  const BoxRec *__restrict__ rec,
+                                                  unsigned long long *__restrict__ mask)
+{
+    __shared__ BoxRec colb[64];
+    __shared__ unsigned long long bits[64];
+    __shared__ unsigned short pairs[64 * 64];
+    // linear block id -> (rb, cb) with cb >= rb: row block rb owns (words - rb) blocks
+    // starting at start(rb) = rb*words - rb*(rb-1)/2
+    int rb, cb;
+    {
+        const long long t = blockIdx.x;
+        int lo = 0, hi = words - 1;
+        while (lo < hi) {                       // largest rb with start(rb) <= t
+            const int mid = (lo + hi + 1) >> 1;
+            const long long start = (long long)mid * words - (long long)mid * (mid - 1) / 2;
+            if (start <= t) lo = mid; else hi = mid - 1;
+        }
+        rb = lo;
+        cb = rb + (int)(t - ((long long)rb * words - (long long)rb * (rb - 1) / 2));
+    }
+    {
+        const int lane = threadIdx.x;
+        const int r = rb * 64 + lane;
+        const int cidx = cb * 64 + lane;
+        if (cidx < n) colb[lane] = rec[cidx];
+        bits[lane] = 0ull;
+        __syncthreads();
+        BoxRec me;
+        if (r < n) me = rec[r];
+        // screen: circumscribed circles
+        unsigned long long cand = 0ull;
+        if (r < n) {
+            const int cmax = min(64, n - cb * 64);
+            for (int k = 0; k < cmax; ++k) {
+                const int c = cb * 64 + k;
+                if (c <= r) continue;
+                const double dx = colb[k].u - me.u, dy = colb[k].v - me.v;
+                const double rr = colb[k].rad + me.rad;
+                if (dx * dx + dy * dy <= rr * rr) cand |= 1ull << k;
+            }
+        }
+        // compact the candidate pairs of the whole wave into LDS
+        const int mine = __builtin_popcountll(cand);
+        int incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        int pos = incl - mine;
+        const int total = __shfl(incl, 63);
+        unsigned long long cc = cand;
+        while (cc) {
+            const int k = __builtin_ctzll(cc);
+            cc &= cc - 1;
+            pairs[pos++] = (unsigned short)((lane << 6) | k);
+        }
+        __syncthreads();
+        for (int e = lane; e < total; e += 64) {
+            const int pr = pairs[e] >> 6, pk = pairs[e] & 63;
+            const BoxRec a = rec[rb * 64 + pr];
+            const BoxRec &bq = colb[pk];
+            const double ia = rect_intersection(a, bq);
+            const double iou = ia * 1.0 / (a.area + bq.area - ia + 0.0000001);   // nms_rotate.py:68
+            if (iou >= thr) atomicOr(&bits[pr], 1ull << pk);                       // :70
+        }
+        __syncthreads();
+        if (r < n) mask[(size_t)r * words + cb] = bits[lane];
+    }
+}
+
+// thr <= 0 suppresses pairs with zero overlap too (0 >= thr): handled by a dense kernel.
+__global__ __launch_bounds__(64) void mask_all_kernel(int n, int words,
+                                                      unsigned long long *__restrict__ mask)
+{
+    const long long total = (long long)n * words;
+    for (long long e = blockIdx.x * 64ll + threadIdx.x; e < total; e += gridDim.x * 64ll) {
+        const int r = (int)(e / words), w = (int)(e - (long long)r * words);
+        unsigned long long v = 0ull;
+        const int c0 = w * 64;
+        for (int k = 0; k < 64; ++k) {
+            const int c = c0 + k;
+            if (c > r && c < n) v |= 1ull << k;
+        }
+        mask[e] = v;
+    }
+}
+
+// Serial sweep by one wave.  `removed` lives in LDS (words <= SWEEP_MAX_WORDS).
+constexpr int SWEEP_MAX_WORDS = 8192;   // n <= 524288
+
+__global__ __launch_bounds__(64) void sweep_kernel(int n, int words, int max_out,
+                                                   const unsigned long long *__restrict__ mask,
+                                                   const int *__restrict__ order,
+                                                   long long *__restrict__ keep,
+                                                   int *__restrict__ n_keep)
+{
+    __shared__ unsigned long long removed[SWEEP_MAX_WORDS];
+    const int lane = threadIdx.x;
+    for (int w = lane; w < words; w += 64) {
+        // bits beyond n are "removed" so the scan never selects them
+        const int valid = n - w * 64;
+        const unsigned long long v = valid >= 64 ? 0ull : (valid <= 0 ? ~0ull : (~0ull << valid));
+        removed[w] = v;
+    }
+    __syncthreads();
+    int nk = 0;
+    int cur = 0;                                 // first rank not yet examined
+    while (nk < max_out && cur < n) {
+        // find the first zero bit at position >= cur, 64 words per step
+        int found = -1;
+        for (int w0 = cur >> 6; w0 < words && found < 0; w0 += 64) {
+            const int w = w0 + lane;
+            unsigned long long z = w < words ? ~removed[w] : 0ull;
+            if (w == (cur >> 6)) z &= ~0ull << (cur & 63);
+            const unsigned long long has = __ballot(z != 0ull);
+            if (has) {
+                const int fl = __builtin_ctzll(has);
+                const int bit = __builtin_ctzll(__shfl(z, fl) | 0ull);
+                found = (w0 + fl) * 64 + bit;
+            }
+        }
+        if (found < 0 || found >= n) break;
+        if (lane == 0) keep[nk] = order[found];
+        ++nk;
+        // removed |= mask row of `found` (only words >= found/64 matter)
+        const unsigned long long *row = mask + (size_t)found * words;
+        for (int w = (found >> 6) + lane; w < words; w += 64) removed[w] |= row[w];
+        __syncthreads();
+        cur = found + 1;
+    }
+    if (lane == 0) *n_keep = nk;
+}
+
+struct NmsLayout {
+    size_t order_off, rec_off, mask_off, total;
+    int words;
+};
+static NmsLayout nms_layout(int n)
+{
+    NmsLayout L;
+    L.words = (n + 63) / 64;
+    size_t off = 0;
+    L.order_off = off; off += ((size_t)n * sizeof(int) + 255) & ~(size_t)255;
+    L.rec_off = off; off += ((size_t)n * sizeof(BoxRec) + 255) & ~(size_t)255;
+    L.mask_off = off; off += (size_t)n * L.words * sizeof(unsigned long long);
+    L.total = off + 256;
+    return L;
+}
+
+}  // namespace prcnn
+
+extern "C" size_t prcnn_nms_rotate_workspace_bytes(int n)
+{
+    if (n <= 0) return 256;
+    return prcnn::nms_layout(n).total;
+}
+
+extern "C" int prcnn_nms_rotate(int n, const double *boxes, const double *scores,
+                                double iou_threshold, int max_output_size, int64_t *keep,
+                                int *n_keep, void *workspace, size_t workspace_bytes,
+                                prcnn_stream_t stream)
+{
+    using namespace prcnn;
+    if (n < 0) return PRCNN_BAD_SHAPE;
+    if (!n_keep) return PRCNN_BAD_SHAPE;
+    hipStream_t st = to_stream(stream);
+    if (n == 0 || max_output_size <= 0) {
+        if (hipMemsetAsync(n_keep, 0, sizeof(int), st) != hipSuccess) return PRCNN_HIP_ERROR;
+        return PRCNN_OK;
+    }
+    if (!boxes || !scores || !keep) return PRCNN_BAD_SHAPE;
+    const NmsLayout L = nms_layout(n);
+    if (L.words > SWEEP_MAX_WORDS) return PRCNN_UNSUPPORTED;
+    if (!workspace || workspace_bytes < L.total) return PRCNN_WORKSPACE;
+    if (((uintptr_t)workspace & 255) != 0) return PRCNN_WORKSPACE;
+    char *ws = (char *)workspace;
+    int *order = (int *)(ws + L.order_off);
+    BoxRec *rec = (BoxRec *)(ws + L.rec_off);
+    unsigned long long *mask = (unsigned long long *)(ws + L.mask_off);
+
+    hipLaunchKernelGGL(rank_kernel, dim3((n + RANK_THREADS - 1) / RANK_THREADS), dim3(RANK_THREADS), 0,
+                       st, n, boxes, scores, order, rec);
+    PRCNN_LAUNCH_CHECK();
+    if (iou_threshold > 0.0) {
+        const long long nblk = (long long)L.words * (L.words + 1) / 2;
+        // lower-triangle words are never read by the sweep (it starts at found/64) except
+        // the diagonal block, which the kernel writes.
+        hipLaunchKernelGGL(mask_kernel, dim3((unsigned)nblk), dim3(64), 0, st, n, L.words,
+                           iou_threshold, rec, mask);
+    } else {
+        hipLaunchKernelGGL(mask_all_kernel, dim3(2048), dim3(64), 0, st, n, L.words, mask);
+    }
+    PRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sweep_kernel, dim3(1), dim3(64), 0, st, n, L.words, max_output_size, mask,
+                       order, (long long *)keep, n_keep);
+    PRCNN_LAUNCH_CHECK();
+    return PRCNN_OK;
+}

@@ -1,0 +1,237 @@
+"""Reference call surface of the PointNet++ primitive ops on torch-ROCm tensors.
+
+Same names, argument order and result shapes as the reference's TF wrappers:
+  models/tf_ops/sampling/tf_sampling.py:30-57      gather_point, farthest_point_sample
+  models/tf_ops/grouping/tf_grouping.py:9-42        query_ball_point, group_point
+  models/tf_ops/3d_interpolation/tf_interpolate.py:9-29   three_nn, three_interpolate
+Tensors are containers only: every op is one call into libpointrcnn_hip.so on the
+current torch stream (no eager fallback; a missing library or a CPU tensor raises).
+Shape errors raise ValueError, mirroring the OP_REQUIRES checks of the reference's
+tf_*.cpp shims.
+"""
+import torch
+
+from . import _lib
+
+PRECISION_FP32 = 0
+PRECISION_BF16 = 1
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, dtype, name, ndim=None, last=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise _lib.PointRCNNHipError("%s must live on the GPU (no CPU path exists)" % name)
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError("%s expects a %d-D tensor, got shape %s" % (name, ndim, tuple(t.shape)))
+    if last is not None and t.shape[-1] != last:
+        raise ValueError("%s expects last dimension %d, got shape %s" % (name, last, tuple(t.shape)))
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+# ---- sampling ---------------------------------------------------------------------------
+
+def farthest_point_sample(npoint, inp):
+    """tf_sampling.py:49-57.  inp (b,n,3) f32 -> (b,npoint) int32."""
+    inp = _dev(inp, torch.float32, "FarthestPointSample inp", 3, 3)   # tf_sampling.cpp:105
+    b, n, _ = inp.shape
+    npoint = int(npoint)
+    out = torch.empty((b, max(npoint, 0)), dtype=torch.int32, device=inp.device)
+    L = _lib.lib()
+    tb = L.prcnn_fps_temp_bytes(b, n)
+    temp = torch.empty(tb // 4, dtype=torch.float32, device=inp.device) if tb else None
+    _lib.check(L.prcnn_farthest_point_sample(b, n, npoint, _p(inp), _p(temp), _p(out), _stream()),
+               "FarthestPointSample")
+    return out
+
+
+def gather_point(inp, idx):
+    """tf_sampling.py:30-38.  inp (b,n,3), idx (b,m) -> (b,m,3)."""
+    inp = _dev(inp, torch.float32, "GatherPoint inp", 3, 3)            # tf_sampling.cpp:131
+    idx = _dev(idx, torch.int32, "GatherPoint idx", 2)                 # tf_sampling.cpp:135
+    if idx.shape[0] != inp.shape[0]:
+        raise ValueError("GatherPoint expects idx batch %d, got %d" % (inp.shape[0], idx.shape[0]))
+    b, n, _ = inp.shape
+    m = idx.shape[1]
+    out = torch.empty((b, m, 3), dtype=torch.float32, device=inp.device)
+    _lib.check(_lib.lib().prcnn_gather_point(b, n, m, _p(inp), _p(idx), _p(out), _stream()),
+               "GatherPoint")
+    return out
+
+
+# ---- grouping ---------------------------------------------------------------------------
+
+def query_ball_point(radius, nsample, xyz1, xyz2):
+    """tf_grouping.py:9-21.  xyz1 (b,n,3) points, xyz2 (b,m,3) queries ->
+    idx (b,m,nsample) int32, pts_cnt (b,m) int32.  idx is zero-initialised, so the rows
+    the reference leaves unwritten (no point in the ball) read 0."""
+    xyz1 = _dev(xyz1, torch.float32, "QueryBallPoint xyz1", 3, 3)      # tf_grouping.cpp:79
+    xyz2 = _dev(xyz2, torch.float32, "QueryBallPoint xyz2", 3, 3)      # tf_grouping.cpp:84
+    if xyz1.shape[0] != xyz2.shape[0]:
+        raise ValueError("QueryBallPoint expects equal batch sizes")
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    nsample = int(nsample)
+    idx = torch.zeros((b, m, max(nsample, 0)), dtype=torch.int32, device=xyz1.device)
+    cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
+    _lib.check(_lib.lib().prcnn_query_ball_point(b, n, m, float(radius), nsample, _p(xyz1), _p(xyz2),
+                                                 _p(idx), _p(cnt), _stream()), "QueryBallPoint")
+    return idx, cnt
+
+
+def group_point(points, idx):
+    """tf_grouping.py:34-42.  points (b,n,c), idx (b,m,nsample) -> (b,m,nsample,c)."""
+    points = _dev(points, torch.float32, "GroupPoint points", 3)       # tf_grouping.cpp:147
+    idx = _dev(idx, torch.int32, "GroupPoint idx", 3)                  # tf_grouping.cpp:153
+    if idx.shape[0] != points.shape[0]:
+        raise ValueError("GroupPoint expects equal batch sizes")
+    b, n, c = points.shape
+    _, m, ns = idx.shape
+    out = torch.empty((b, m, ns, c), dtype=torch.float32, device=points.device)
+    _lib.check(_lib.lib().prcnn_group_point(b, n, c, m, ns, _p(points), _p(idx), _p(out), _stream()),
+               "GroupPoint")
+    return out
+
+
+# ---- 3d_interpolation -------------------------------------------------------------------
+
+def three_nn(xyz1, xyz2):
+    """tf_interpolate.py:9-18.  xyz1 (b,n,3) unknown, xyz2 (b,m,3) known ->
+    dist (b,n,3) f32 SQUARED distances, idx (b,n,3) int32."""
+    xyz1 = _dev(xyz1, torch.float32, "ThreeNN xyz1", 3, 3)             # tf_interpolate.cpp:163
+    xyz2 = _dev(xyz2, torch.float32, "ThreeNN xyz2", 3, 3)             # tf_interpolate.cpp:168
+    if xyz1.shape[0] != xyz2.shape[0]:
+        raise ValueError("ThreeNN expects equal batch sizes")
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    dist = torch.empty((b, n, 3), dtype=torch.float32, device=xyz1.device)
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=xyz1.device)
+    _lib.check(_lib.lib().prcnn_three_nn(b, n, m, _p(xyz1), _p(xyz2), _p(dist), _p(idx), _stream()),
+               "ThreeNN")
+    return dist, idx
+
+
+def three_interpolate(points, idx, weight):
+    """tf_interpolate.py:20-29.  points (b,m,c), idx/weight (b,n,3) -> (b,n,c)."""
+    points = _dev(points, torch.float32, "ThreeInterpolate points", 3)          # :203
+    idx = _dev(idx, torch.int32, "ThreeInterpolate idx", 3, 3)                  # :206
+    weight = _dev(weight, torch.float32, "ThreeInterpolate weight", 3, 3)
+    if idx.shape != weight.shape or idx.shape[0] != points.shape[0]:
+        raise ValueError("ThreeInterpolate expects idx/weight of equal shape (b,n,3)")
+    b, m, c = points.shape
+    n = idx.shape[1]
+    out = torch.empty((b, n, c), dtype=torch.float32, device=points.device)
+    _lib.check(_lib.lib().prcnn_three_interpolate(b, m, c, n, _p(points), _p(idx), _p(weight),
+                                                  _p(out), _stream()), "ThreeInterpolate")
+    return out
+
+
+def fp_weights(dist):
+    """models/pointnet_util.py:211-214: inverse-distance weights from three_nn's dist."""
+    dist = _dev(dist, torch.float32, "fp_weights dist", None, 3)
+    w = torch.empty_like(dist)
+    _lib.check(_lib.lib().prcnn_fp_weights(dist.numel() // 3, _p(dist), _p(w), _stream()), "fp_weights")
+    return w
+
+
+def three_nn_interpolate(xyz1, xyz2, points2, out=None, return_nn=False):
+    """Fused pointnet_util.py:210-215.  Writes (b,n,c) into `out[..., :c]` when a
+    wider (b,n,ldo) float32 buffer is given (the FP concat buffer of :218)."""
+    xyz1 = _dev(xyz1, torch.float32, "three_nn_interpolate xyz1", 3, 3)
+    xyz2 = _dev(xyz2, torch.float32, "three_nn_interpolate xyz2", 3, 3)
+    points2 = _dev(points2, torch.float32, "three_nn_interpolate points2", 3)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    c = points2.shape[2]
+    if xyz2.shape[0] != b or points2.shape[0] != b or points2.shape[1] != m:
+        raise ValueError("three_nn_interpolate expects xyz2 (b,m,3) and points2 (b,m,c)")
+    if out is None:
+        out = torch.empty((b, n, c), dtype=torch.float32, device=xyz1.device)
+    if (not out.is_cuda or out.dtype != torch.float32 or not out.is_contiguous()
+            or out.shape[:2] != (b, n) or out.shape[2] < c):
+        raise ValueError("three_nn_interpolate: out must be a contiguous (b,n,>=c) float32 GPU tensor")
+    dist = idx = None
+    if return_nn:
+        dist = torch.empty((b, n, 3), dtype=torch.float32, device=xyz1.device)
+        idx = torch.empty((b, n, 3), dtype=torch.int32, device=xyz1.device)
+    _lib.check(_lib.lib().prcnn_three_nn_interpolate(b, n, m, c, _p(xyz1), _p(xyz2), _p(points2), _p(out),
+                                                     out.shape[2], _p(dist), _p(idx), _stream()),
+               "three_nn_interpolate")
+    return (out, dist, idx) if return_nn else out
+
+
+# ---- shared MLP -------------------------------------------------------------------------
+
+def mlp_layer(x, w, scale, shift, relu=True, pool=1, precision=PRECISION_FP32, out=None, out_col=0):
+    """One shared-MLP layer (tf_util.py:120-185 with BN folded) on the matrix cores.
+    x (..., cin) -> (..., cout), or (rows/pool, cout) when pool > 1."""
+    x = _dev(x, torch.float32, "mlp_layer x")
+    w = _dev(w, torch.float32, "mlp_layer w", 2)
+    scale = _dev(scale, torch.float32, "mlp_layer scale", 1)
+    shift = _dev(shift, torch.float32, "mlp_layer shift", 1)
+    cin, cout = w.shape
+    if x.shape[-1] != cin:
+        raise ValueError("mlp_layer: x has %d channels, w expects %d" % (x.shape[-1], cin))
+    rows = x.numel() // cin
+    L = _lib.lib()
+    if pool > 1 and (pool % 16 != 0 or 128 % pool != 0):
+        # group sizes the fused epilogue does not cover: layer, then the pooling kernel
+        y = mlp_layer(x, w, scale, shift, relu, 1, precision)
+        res = torch.empty((rows // pool, cout), dtype=torch.float32, device=x.device)
+        _lib.check(L.prcnn_max_pool(rows // pool, pool, cout, _p(y), cout, _p(res), cout, _stream()),
+                   "max_pool")
+        return res
+    if out is None:
+        shape = (rows // pool, cout) if pool > 1 else tuple(x.shape[:-1]) + (cout,)
+        res = torch.empty(shape, dtype=torch.float32, device=x.device)
+        optr, ldo = res.data_ptr(), cout
+    else:
+        res = out
+        ldo = out.shape[-1]
+        optr = out.data_ptr() + 4 * out_col
+    _lib.check(L.prcnn_mlp_layer(rows, cin, cout, _p(x), cin, _p(w), _p(scale), _p(shift), int(relu),
+                                 int(pool), int(precision), optr, ldo, _stream()), "mlp_layer")
+    return res
+
+
+def sa_group_mlp_layer(xyz, feats, new_xyz, idx, w, scale, shift, xyz_first=False, relu=True, pool=1,
+                       precision=PRECISION_FP32):
+    """group_point + centre + concat + first shared-MLP layer in one launch
+    (pointnet_util.py:177-190 MSG / :43-53 SSG).  Returns (b,m,nsample,cout), or
+    (b,m,cout) when pool == nsample."""
+    xyz = _dev(xyz, torch.float32, "sa_group_mlp_layer xyz", 3, 3)
+    new_xyz = _dev(new_xyz, torch.float32, "sa_group_mlp_layer new_xyz", 3, 3)
+    idx = _dev(idx, torch.int32, "sa_group_mlp_layer idx", 3)
+    b, n, _ = xyz.shape
+    _, m, ns = idx.shape
+    c = 0
+    if feats is not None:
+        feats = _dev(feats, torch.float32, "sa_group_mlp_layer feats", 3)
+        c = feats.shape[2]
+    w = _dev(w, torch.float32, "sa_group_mlp_layer w", 2)
+    scale = _dev(scale, torch.float32, "scale", 1)
+    shift = _dev(shift, torch.float32, "shift", 1)
+    cout = w.shape[1]
+    if w.shape[0] != c + 3:
+        raise ValueError("sa_group_mlp_layer: w has %d rows, expected %d" % (w.shape[0], c + 3))
+    if pool > 1:
+        if pool != ns:
+            raise ValueError("sa_group_mlp_layer: pool must equal nsample")
+        out = torch.empty((b, m, cout), dtype=torch.float32, device=xyz.device)
+    else:
+        out = torch.empty((b, m, ns, cout), dtype=torch.float32, device=xyz.device)
+    _lib.check(_lib.lib().prcnn_sa_group_mlp_layer(
+        b, n, m, ns, c, _p(xyz), _p(feats), _p(new_xyz), _p(idx), int(bool(xyz_first)), cout, _p(w),
+        _p(scale), _p(shift), int(relu), int(pool), int(precision), _p(out), cout, _stream()),
+        "sa_group_mlp_layer")
+    return out

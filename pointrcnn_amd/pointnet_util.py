@@ -1,0 +1,256 @@
+"""PointNet++ set-abstraction / feature-propagation layers on the gfx950 ops.
+
+Host-side mirror of the reference's models/pointnet_util.py with the same function
+names and argument lists:
+  sample_and_group            :21-55      sample_and_group_all        :58-83
+  pointnet_sa_module          :86-153     pointnet_sa_module_msg      :155-195
+  pointnet_fp_module          :198-228
+Inference only (is_training must be False): tf_util.conv2d's conv + bias + batch_norm
+(models/tf_util.py:120-185,512-531, eps 1e-3) is folded into one (W, scale, shift)
+triple per layer, looked up in a ParamStore under the TF variable-scope name the
+reference would have used ('<scope>/conv0', '<scope>/conv1_2', '<scope>/conv_0').
+
+Two execution modes, same results (tests/test_pointnet_util.py):
+  FUSED = True   grouping is fused into the first shared-MLP layer and the max-pool into
+                 the last one; FP uses the fused three_nn+interpolate kernel writing
+                 straight into the concat buffer.  The (b,m,nsample,C) tensor never exists.
+  FUSED = False  the reference's op-by-op composition (group_point, concat, ...).
+Options of the reference that no caller uses raise NotImplementedError (pooling other
+than 'max', mlp2, knn, use_nchw).
+"""
+import math
+
+import torch
+
+from . import ops
+
+FUSED = True
+PRECISION = ops.PRECISION_FP32
+
+
+class ParamStore(dict):
+    """scope name -> (W (cin,cout), scale (cout,), shift (cout,)) float32 GPU tensors."""
+
+    def __init__(self, seed=7, device="cuda", randomize_bn=False):
+        super().__init__()
+        self.gen = torch.Generator(device="cpu")
+        self.gen.manual_seed(seed)
+        self.device = device
+        self.randomize_bn = randomize_bn
+
+    def layer(self, name, cin, cout, bn=True):
+        if name not in self:
+            lim = math.sqrt(6.0 / (cin + cout))                     # xavier_initializer
+            W = (torch.rand((cin, cout), generator=self.gen) * 2 - 1) * lim
+            if self.randomize_bn:
+                gamma = torch.rand(cout, generator=self.gen) + 0.5
+                beta = torch.randn(cout, generator=self.gen) * 0.1
+                mean = torch.randn(cout, generator=self.gen) * 0.1
+                var = torch.rand(cout, generator=self.gen) + 0.5
+                bias = torch.randn(cout, generator=self.gen) * 0.05
+            else:
+                gamma, beta = torch.ones(cout), torch.zeros(cout)
+                mean, var, bias = torch.zeros(cout), torch.ones(cout), torch.zeros(cout)
+            self[name] = fold_bn(W, bias, gamma, beta, mean, var, bn=bn, device=self.device)
+        W, s, t = self[name]
+        if W.shape != (cin, cout):
+            raise ValueError("%s: stored weight %s does not match (%d,%d)" % (name, tuple(W.shape), cin, cout))
+        return W, s, t
+
+
+def fold_bn(W, bias, gamma, beta, mean, var, eps=1e-3, bn=True, device="cuda"):
+    """relu(BN(x.W + bias)) == relu(scale * (x.W) + shift)   (tf_util.py:170-184,:527)."""
+    if bn:
+        scale = gamma / torch.sqrt(var + eps)
+        shift = beta + (bias - mean) * scale
+    else:
+        scale = torch.ones_like(bias)
+        shift = bias.clone()
+    f = lambda t: t.to(device=device, dtype=torch.float32).contiguous()
+    return f(W), f(scale), f(shift)
+
+
+_PARAMS = None
+
+
+def set_params(store):
+    global _PARAMS
+    _PARAMS = store
+    return store
+
+
+def get_params():
+    global _PARAMS
+    if _PARAMS is None:
+        _PARAMS = ParamStore()
+    return _PARAMS
+
+
+def _check_inference(is_training):
+    if bool(is_training):
+        raise NotImplementedError("inference only: is_training must be False (gradients are a 'next' row)")
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True):
+    """models/pointnet_util.py:21-55 -> new_xyz, new_points, idx, grouped_xyz."""
+    if knn:
+        raise NotImplementedError("knn grouping is never enabled by the reference's callers")
+    new_xyz = ops.gather_point(xyz, ops.farthest_point_sample(npoint, xyz))
+    idx, pts_cnt = ops.query_ball_point(radius, nsample, xyz, new_xyz)
+    grouped_xyz = ops.group_point(xyz, idx)
+    grouped_xyz = grouped_xyz - new_xyz.unsqueeze(2)                 # translation normalisation
+    if points is not None:
+        grouped_points = ops.group_point(points, idx)
+        new_points = torch.cat([grouped_xyz, grouped_points], dim=-1) if use_xyz else grouped_points
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def sample_and_group_all(xyz, points, use_xyz=True):
+    """models/pointnet_util.py:58-83: one group holding every point, centroid (0,0,0), xyz un-centred."""
+    b, n, _ = xyz.shape
+    new_xyz = torch.zeros((b, 1, 3), dtype=torch.float32, device=xyz.device)
+    idx = torch.arange(n, dtype=torch.int32, device=xyz.device).view(1, 1, n).repeat(b, 1, 1)
+    grouped_xyz = xyz.reshape(b, 1, n, 3)
+    if points is not None:
+        new_points = torch.cat([xyz, points], dim=2) if use_xyz else points
+        new_points = new_points.unsqueeze(1)
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def _mlp_chain(x, names_dims, store, bn, pool, precision):
+    """x (..., cin) through the layers; the max-pool is fused into the last layer."""
+    for li, (name, cin, cout) in enumerate(names_dims):
+        W, s, t = store.layer(name, cin, cout, bn)
+        last = li == len(names_dims) - 1
+        x = ops.mlp_layer(x, W, s, t, relu=True, pool=pool if last else 1, precision=precision)
+    return x
+
+
+def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, is_training,
+                       bn_decay, scope, bn=True, pooling='max', knn=False, use_xyz=True,
+                       use_nchw=False, params=None, precision=None):
+    """models/pointnet_util.py:86-153 -> new_xyz (b,npoint,3), new_points (b,npoint,mlp[-1]), idx."""
+    _check_inference(is_training)
+    if pooling != 'max' or mlp2 is not None or knn or use_nchw:
+        raise NotImplementedError("only pooling='max', mlp2=None, knn=False, NHWC are used by the reference")
+    store = params if params is not None else get_params()
+    precision = PRECISION if precision is None else precision
+    b = xyz.shape[0]
+    if group_all:
+        nsample = xyz.shape[1]
+        new_xyz, new_points, idx, _ = sample_and_group_all(xyz, points, use_xyz)
+        cin = new_points.shape[-1]
+        dims, c = [], cin
+        for i, co in enumerate(mlp):
+            dims.append(('%s/conv%d' % (scope, i), c, co)); c = co
+        out = _mlp_chain(new_points.reshape(b * nsample, cin), dims, store, bn, nsample, precision)
+        return new_xyz, out.reshape(b, 1, mlp[-1]), idx
+    c_feat = 0 if points is None else points.shape[2]
+    if FUSED and (use_xyz or points is None) and nsample % 16 == 0 and 128 % nsample == 0:
+        new_xyz = ops.gather_point(xyz, ops.farthest_point_sample(npoint, xyz))
+        idx, _ = ops.query_ball_point(radius, nsample, xyz, new_xyz)
+        W, s, t = store.layer('%s/conv0' % scope, c_feat + 3, mlp[0], bn)
+        x = ops.sa_group_mlp_layer(xyz, points, new_xyz, idx, W, s, t, xyz_first=True, relu=True,
+                                   pool=nsample if len(mlp) == 1 else 1, precision=precision)
+        dims, c = [], mlp[0]
+        for i, co in enumerate(mlp[1:], 1):
+            dims.append(('%s/conv%d' % (scope, i), c, co)); c = co
+        if dims:
+            x = _mlp_chain(x.reshape(-1, mlp[0]), dims, store, bn, nsample, precision)
+        return new_xyz, x.reshape(b, npoint, mlp[-1]), idx
+    new_xyz, new_points, idx, _ = sample_and_group(npoint, radius, nsample, xyz, points, knn, use_xyz)
+    cin = new_points.shape[-1]
+    dims, c = [], cin
+    for i, co in enumerate(mlp):
+        dims.append(('%s/conv%d' % (scope, i), c, co)); c = co
+    out = _mlp_chain(new_points.reshape(-1, cin), dims, store, bn, nsample, precision)
+    return new_xyz, out.reshape(b, npoint, mlp[-1]), idx
+
+
+def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_list, is_training,
+                           bn_decay, scope, bn=True, use_xyz=True, use_nchw=False, params=None,
+                           precision=None):
+    """models/pointnet_util.py:155-195 -> new_xyz (b,npoint,3), new_points (b,npoint,sum mlp[k][-1]).
+    Channel order inside each scale is [features, xyz_local] (:183)."""
+    _check_inference(is_training)
+    if use_nchw:
+        raise NotImplementedError("use_nchw is never set by the reference's callers")
+    store = params if params is not None else get_params()
+    precision = PRECISION if precision is None else precision
+    b = xyz.shape[0]
+    new_xyz = ops.gather_point(xyz, ops.farthest_point_sample(npoint, xyz))
+    ctot = sum(m[-1] for m in mlp_list)
+    out = torch.empty((b, npoint, ctot), dtype=torch.float32, device=xyz.device)
+    col = 0
+    c_feat = 0 if points is None else points.shape[2]
+    for i in range(len(radius_list)):
+        radius, nsample, mlp = radius_list[i], nsample_list[i], mlp_list[i]
+        idx, pts_cnt = ops.query_ball_point(radius, nsample, xyz, new_xyz)
+        fusable = FUSED and (use_xyz or points is None) and nsample % 16 == 0 and 128 % nsample == 0
+        if fusable:
+            W, s, t = store.layer('%s/conv%d_0' % (scope, i), c_feat + 3, mlp[0], bn)
+            x = ops.sa_group_mlp_layer(xyz, points, new_xyz, idx, W, s, t, xyz_first=False, relu=True,
+                                       pool=nsample if len(mlp) == 1 else 1, precision=precision)
+            x = x.reshape(-1, mlp[0])
+            start, c = 1, mlp[0]
+        else:
+            grouped_xyz = ops.group_point(xyz, idx) - new_xyz.unsqueeze(2)
+            if points is not None:
+                grouped_points = ops.group_point(points, idx)
+                if use_xyz:
+                    grouped_points = torch.cat([grouped_points, grouped_xyz], dim=-1)
+            else:
+                grouped_points = grouped_xyz
+            c = grouped_points.shape[-1]
+            x = grouped_points.reshape(-1, c)
+            start = 0
+        for j in range(start, len(mlp)):
+            W, s, t = store.layer('%s/conv%d_%d' % (scope, i, j), c, mlp[j], bn)
+            last = j == len(mlp) - 1
+            if last:   # pooled result goes straight into its slice of the concat (:194)
+                if nsample % 16 == 0 and 128 % nsample == 0:
+                    ops.mlp_layer(x, W, s, t, relu=True, pool=nsample, precision=precision,
+                                  out=out, out_col=col)
+                else:
+                    out[:, :, col:col + mlp[j]] = ops.mlp_layer(
+                        x, W, s, t, relu=True, pool=nsample, precision=precision).reshape(b, npoint, -1)
+            else:
+                x = ops.mlp_layer(x, W, s, t, relu=True, precision=precision)
+            c = mlp[j]
+        if len(mlp) == 1 and fusable:
+            out[:, :, col:col + mlp[0]] = x.reshape(b, npoint, -1)
+        col += mlp[-1]
+    return new_xyz, out
+
+
+def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True,
+                       params=None, precision=None):
+    """models/pointnet_util.py:198-228 -> (b, ndataset1, mlp[-1])."""
+    _check_inference(is_training)
+    store = params if params is not None else get_params()
+    precision = PRECISION if precision is None else precision
+    b, n, _ = xyz1.shape
+    c2 = points2.shape[2]
+    if FUSED:
+        c1 = 0 if points1 is None else points1.shape[2]
+        new_points1 = torch.empty((b, n, c2 + c1), dtype=torch.float32, device=xyz1.device)
+        ops.three_nn_interpolate(xyz1, xyz2, points2, out=new_points1)
+        if points1 is not None:
+            new_points1[:, :, c2:] = points1
+    else:
+        dist, idx = ops.three_nn(xyz1, xyz2)
+        weight = ops.fp_weights(dist)
+        interpolated_points = ops.three_interpolate(points2, idx, weight)
+        new_points1 = (torch.cat([interpolated_points, points1], dim=2)
+                       if points1 is not None else interpolated_points)
+    c = new_points1.shape[2]
+    x = new_points1.reshape(b * n, c)
+    for i, co in enumerate(mlp):
+        W, s, t = store.layer('%s/conv_%d' % (scope, i), c, co, bn)
+        x = ops.mlp_layer(x, W, s, t, relu=True, precision=precision)
+        c = co
+    return x.reshape(b, n, mlp[-1])

@@ -1,0 +1,111 @@
+"""The SA/FP stacks of the reference's models, expressed with pointnet_util.
+
+Only the set-abstraction / feature-propagation backbones are here (the hot path); heads,
+losses and box decoding are out of scope.  Hyper-parameters are the
+reference's literals:
+  rpn_sa_fp_stack        models/rpn.py:159-192           (RPN backbone, 4 SA-MSG + 4 FP)
+  frustum_cls_stack      models/frustum_pointnets_v2.py:131-142
+  frustum_seg_stack      models/frustum_pointnets_v2.py:212-234
+  frustum_box_stack      models/frustum_pointnets_v2.py:272-283
+"""
+import torch
+
+from .pointnet_util import pointnet_fp_module, pointnet_sa_module, pointnet_sa_module_msg
+
+# (npoint, radii, nsamples, mlps) per SA-MSG level, models/rpn.py:166-181
+RPN_SA = [
+    (4096, [0.1, 0.5], [16, 32], [[16, 16, 32], [32, 32, 64]]),
+    (1024, [0.5, 1.0], [16, 32], [[64, 64, 128], [64, 96, 128]]),
+    (256, [1.0, 2.0], [16, 32], [[128, 196, 256], [128, 196, 256]]),
+    (64, [2.0, 4.0], [16, 32], [[256, 256, 512], [256, 384, 512]]),
+]
+# mlp per FP level, models/rpn.py:184-192
+RPN_FP = [[512, 512], [512, 512], [256, 256], [128, 128]]
+
+
+def rpn_sa_fp_stack(point_cloud, params=None, precision=None, is_training=False, bn_decay=None):
+    """point_cloud (B,N,4) -> per-point features (B,N,128); also returns the level xyz/feature lists."""
+    l0_xyz = point_cloud[:, :, 0:3].contiguous()
+    l0_points = point_cloud[:, :, 3:].contiguous() if point_cloud.shape[2] > 3 else None
+    xyzs, feats = [l0_xyz], [l0_points]
+    for li, (npoint, radii, nsamples, mlps) in enumerate(RPN_SA):
+        x, f = pointnet_sa_module_msg(xyzs[-1], feats[-1], npoint, radii, nsamples, mlps, is_training,
+                                      bn_decay, scope='layer%d' % (li + 1), bn=True, params=params,
+                                      precision=precision)
+        xyzs.append(x)
+        feats.append(f)
+    l3 = pointnet_fp_module(xyzs[3], xyzs[4], feats[3], feats[4], RPN_FP[0], is_training, bn_decay,
+                            scope='fa_layer2', bn=True, params=params, precision=precision)
+    l2 = pointnet_fp_module(xyzs[2], xyzs[3], feats[2], l3, RPN_FP[1], is_training, bn_decay,
+                            scope='fa_layer3', bn=True, params=params, precision=precision)
+    l1 = pointnet_fp_module(xyzs[1], xyzs[2], feats[1], l2, RPN_FP[2], is_training, bn_decay,
+                            scope='fa_layer4', bn=True, params=params, precision=precision)
+    p1 = torch.cat([l0_xyz, l0_points], dim=-1) if l0_points is not None else l0_xyz
+    l0 = pointnet_fp_module(l0_xyz, xyzs[1], p1, l1, RPN_FP[3], is_training, bn_decay,
+                            scope='fa_layer5', bn=True, params=params, precision=precision)
+    return l0, {"xyz": xyzs, "sa_feats": feats, "fp_feats": [l3, l2, l1, l0]}
+
+
+def _frustum_msg_trunk(l0_xyz, l0_points, prefix, params, precision):
+    l1_xyz, l1_points = pointnet_sa_module_msg(
+        l0_xyz, l0_points, 128, [0.2, 0.4, 0.8], [32, 64, 128],
+        [[32, 32, 64], [64, 64, 128], [64, 96, 128]], False, None, scope=prefix + 'layer1',
+        params=params, precision=precision)
+    l2_xyz, l2_points = pointnet_sa_module_msg(
+        l1_xyz, l1_points, 32, [0.4, 0.8, 1.6], [64, 64, 128],
+        [[64, 64, 128], [128, 128, 256], [128, 128, 256]], False, None, scope=prefix + 'layer2',
+        params=params, precision=precision)
+    return l1_xyz, l1_points, l2_xyz, l2_points
+
+
+def frustum_cls_stack(point_cloud, params=None, precision=None):
+    """models/frustum_pointnets_v2.py:131-142 -> global feature (B,512)."""
+    l0_xyz = point_cloud[:, :, 0:3].contiguous()
+    l0_points = point_cloud[:, :, 3:].contiguous()
+    _, _, l2_xyz, l2_points = _frustum_msg_trunk(l0_xyz, l0_points, 'cls_', params, precision)
+    _, l3_points, _ = pointnet_sa_module(l2_xyz, l2_points, npoint=None, radius=None, nsample=None,
+                                         mlp=[128, 256, 512], mlp2=None, group_all=True,
+                                         is_training=False, bn_decay=None, scope='cls_layer3',
+                                         params=params, precision=precision)
+    return l3_points.reshape(point_cloud.shape[0], -1)
+
+
+def frustum_seg_stack(point_cloud, one_hot_vec, params=None, precision=None):
+    """models/frustum_pointnets_v2.py:212-234 -> per-point features (B,N,128)."""
+    l0_xyz = point_cloud[:, :, 0:3].contiguous()
+    l0_points = point_cloud[:, :, 3:].contiguous()
+    l1_xyz, l1_points, l2_xyz, l2_points = _frustum_msg_trunk(l0_xyz, l0_points, '', params, precision)
+    l3_xyz, l3_points, _ = pointnet_sa_module(l2_xyz, l2_points, npoint=None, radius=None, nsample=None,
+                                              mlp=[128, 256, 1024], mlp2=None, group_all=True,
+                                              is_training=False, bn_decay=None, scope='layer3',
+                                              params=params, precision=precision)
+    l3_points = torch.cat([l3_points, one_hot_vec.unsqueeze(1)], dim=2)          # :226
+    l2_points = pointnet_fp_module(l2_xyz, l3_xyz, l2_points, l3_points, [128, 128], False, None,
+                                   scope='fa_layer1', params=params, precision=precision)
+    l1_points = pointnet_fp_module(l1_xyz, l2_xyz, l1_points, l2_points, [128, 128], False, None,
+                                   scope='fa_layer2', params=params, precision=precision)
+    l0_points = pointnet_fp_module(l0_xyz, l1_xyz, torch.cat([l0_xyz, l0_points], dim=-1), l1_points,
+                                   [128, 128], False, None, scope='fa_layer3', params=params,
+                                   precision=precision)
+    return l0_points
+
+
+def frustum_box_stack(object_point_cloud, params=None, precision=None):
+    """models/frustum_pointnets_v2.py:268-283 (SSG; first layer has points=None when the cloud
+    is xyz only) -> global feature (B,512)."""
+    l0_xyz = object_point_cloud[:, :, 0:3].contiguous()
+    l0_points = (object_point_cloud[:, :, 3:].contiguous()
+                 if object_point_cloud.shape[2] > 3 else None)
+    l1_xyz, l1_points, _ = pointnet_sa_module(l0_xyz, l0_points, npoint=128, radius=0.2, nsample=64,
+                                              mlp=[64, 64, 128], mlp2=None, group_all=False,
+                                              is_training=False, bn_decay=None, scope='ssg-layer1',
+                                              params=params, precision=precision)
+    l2_xyz, l2_points, _ = pointnet_sa_module(l1_xyz, l1_points, npoint=32, radius=0.4, nsample=64,
+                                              mlp=[128, 128, 256], mlp2=None, group_all=False,
+                                              is_training=False, bn_decay=None, scope='ssg-layer2',
+                                              params=params, precision=precision)
+    _, l3_points, _ = pointnet_sa_module(l2_xyz, l2_points, npoint=None, radius=None, nsample=None,
+                                         mlp=[256, 256, 512], mlp2=None, group_all=True,
+                                         is_training=False, bn_decay=None, scope='ssg-layer3',
+                                         params=params, precision=precision)
+    return l3_points.reshape(object_point_cloud.shape[0], -1)

@@ -1,0 +1,202 @@
+"""GPU parity: shared-MLP / fused SA / FP layers vs the float64-accumulating oracle.
+Tolerances (north_star): 1e-5 relative for fp32, 1e-2 for bf16 (relative to the
+largest magnitude of the layer's output, plus the same absolute floor)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from pointrcnn_amd import ops, pointnet_util as PU, stacks, synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+TOL = {ops.PRECISION_FP32: 1e-5, ops.PRECISION_BF16: 1e-2}
+
+
+def dev(a, cuda):
+    return torch.as_tensor(a).to(cuda)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def close(got, ref, prec):
+    tol = TOL[prec]
+    scale = max(float(np.abs(ref).max()), 1e-6)
+    err = float(np.abs(got - ref).max())
+    assert err <= tol * scale, "max err %g vs %g" % (err, tol * scale)
+
+
+def rand_layer(rng, cin, cout):
+    lim = np.sqrt(6.0 / (cin + cout))
+    W = rng.uniform(-lim, lim, (cin, cout)).astype(np.float32)
+    s = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    t = rng.normal(0, 0.1, cout).astype(np.float32)
+    return W, s, t
+
+
+@pytest.mark.parametrize("prec", [ops.PRECISION_FP32, ops.PRECISION_BF16])
+@pytest.mark.parametrize("rows,cin,cout", [(128, 4, 16), (1000, 4, 32), (256, 99, 64), (300, 259, 128),
+                                           (512, 515, 256), (130, 196, 256), (64, 256, 384), (257, 1536, 512),
+                                           (100, 7, 5), (40, 260, 128), (2048, 16, 16), (96, 33, 196)])
+def test_mlp_layer(cuda, prec, rows, cin, cout):
+    rng = np.random.default_rng(rows + cin + cout)
+    x = rng.standard_normal((rows, cin)).astype(np.float32)
+    W, s, t = rand_layer(rng, cin, cout)
+    for relu in (True, False):
+        got = npy(ops.mlp_layer(dev(x, cuda), dev(W, cuda), dev(s, cuda), dev(t, cuda), relu=relu, precision=prec))
+        close(got, O.mlp_layer(x, W, s, t, relu), prec)
+
+
+@pytest.mark.parametrize("prec", [ops.PRECISION_FP32, ops.PRECISION_BF16])
+@pytest.mark.parametrize("groups,ns,cin,cout", [(40, 16, 16, 32), (9, 32, 64, 128), (5, 64, 64, 128),
+                                                (3, 128, 96, 128), (7, 32, 256, 512), (4, 48, 20, 24),
+                                                (2, 1024, 12, 40)])
+def test_mlp_layer_fused_pool(cuda, prec, groups, ns, cin, cout):
+    rng = np.random.default_rng(groups * ns + cin)
+    x = rng.standard_normal((groups * ns, cin)).astype(np.float32)
+    W, s, t = rand_layer(rng, cin, cout)
+    got = npy(ops.mlp_layer(dev(x, cuda), dev(W, cuda), dev(s, cuda), dev(t, cuda), pool=ns, precision=prec))
+    ref = O.max_pool(O.mlp_layer(x, W, s, t).reshape(groups, ns, cout), ns)
+    assert got.shape == (groups, cout)
+    close(got, ref, prec)
+
+
+@pytest.mark.parametrize("prec", [ops.PRECISION_FP32, ops.PRECISION_BF16])
+@pytest.mark.parametrize("c,xyz_first,ns,cout", [(1, False, 16, 16), (96, False, 32, 64), (0, True, 64, 64),
+                                                 (7, True, 16, 40), (256, False, 16, 128), (5, False, 32, 32)])
+def test_sa_group_mlp_layer_equals_materialised_path(cuda, prec, c, xyz_first, ns, cout):
+    rng = np.random.default_rng(c + ns)
+    b, n, m = 2, 700, 50
+    xyz = rng.random((b, n, 3), dtype=np.float32)
+    feats = rng.standard_normal((b, n, c)).astype(np.float32) if c else None
+    fi = O.farthest_point_sample(m, xyz)
+    new_xyz = O.gather_point(xyz, fi)
+    idx, _ = O.query_ball_point(0.25, ns, xyz, new_xyz)
+    W, s, t = rand_layer(rng, c + 3, cout)
+    gx = O.group_point(xyz, idx) - new_xyz[:, :, None, :]
+    if c:
+        gf = O.group_point(feats, idx)
+        rows = np.concatenate([gx, gf] if xyz_first else [gf, gx], -1)
+    else:
+        rows = gx
+    ref = O.mlp_layer(rows, W, s, t)
+    args = (dev(xyz, cuda), None if feats is None else dev(feats, cuda), dev(new_xyz, cuda), dev(idx, cuda),
+            dev(W, cuda), dev(s, cuda), dev(t, cuda))
+    got = npy(ops.sa_group_mlp_layer(*args, xyz_first=xyz_first, precision=prec))
+    assert got.shape == (b, m, ns, cout)
+    close(got, ref, prec)
+    got = npy(ops.sa_group_mlp_layer(*args, xyz_first=xyz_first, pool=ns, precision=prec))
+    close(got, O.max_pool(ref, ns), prec)
+
+
+def _oracle_sa_msg(xyz, points, npoint, radii, nsamples, mlps, layers):
+    new_xyz = O.gather_point(xyz, O.farthest_point_sample(npoint, xyz))
+    outs = []
+    for i, (r, ns) in enumerate(zip(radii, nsamples)):
+        idx, _ = O.query_ball_point(r, ns, xyz, new_xyz)
+        g = O.group_point(xyz, idx) - new_xyz[:, :, None, :]
+        if points is not None:
+            g = np.concatenate([O.group_point(points, idx), g], -1)      # [features, xyz] (:183)
+        for (W, s, t) in layers[i]:
+            g = O.mlp_layer(g, W, s, t)
+        outs.append(O.max_pool(g, ns))
+    return new_xyz, np.concatenate(outs, -1)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_sa_module_msg_matches_oracle_composition(cuda, fused):
+    rng = np.random.default_rng(17)
+    pc = S.kitti_batch(20, 2, 2048)
+    xyz, pts = pc[:, :, :3].copy(), pc[:, :, 3:].copy()
+    radii, nsamples, mlps = [0.5, 1.0], [16, 32], [[16, 16, 32], [32, 32, 64]]
+    store = PU.ParamStore(seed=1, device=cuda, randomize_bn=True)
+    PU.FUSED = fused
+    try:
+        new_xyz, feats = PU.pointnet_sa_module_msg(dev(xyz, cuda), dev(pts, cuda), 256, radii, nsamples, mlps,
+                                                   False, None, scope='layer1', params=store)
+    finally:
+        PU.FUSED = True
+    layers = [[tuple(npy(t) for t in store['layer1/conv%d_%d' % (i, j)]) for j in range(3)] for i in range(2)]
+    oxyz, ofeats = _oracle_sa_msg(xyz, pts, 256, radii, nsamples, mlps, layers)
+    assert np.array_equal(npy(new_xyz), oxyz)
+    close(npy(feats), ofeats, ops.PRECISION_FP32)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_sa_module_ssg_group_all_and_fp_match_oracle(cuda, fused):
+    fr = S.frustum_batch(3, 4, 512, channels=3)
+    xyz = fr[:, :, :3].copy()
+    store = PU.ParamStore(seed=2, device=cuda, randomize_bn=True)
+    PU.FUSED = fused
+    try:
+        x1, p1, idx1 = PU.pointnet_sa_module(dev(xyz, cuda), None, 128, 0.2, 64, [64, 64, 128], None, False,
+                                             False, None, scope='ssg-layer1', params=store)
+        x2, p2, _ = PU.pointnet_sa_module(x1, p1, 32, 0.4, 64, [128, 128, 256], None, False,
+                                          False, None, scope='ssg-layer2', params=store)
+        x3, p3, _ = PU.pointnet_sa_module(x2, p2, None, None, None, [256, 256, 512], None, True,
+                                          False, None, scope='ssg-layer3', params=store)
+        f2 = PU.pointnet_fp_module(x2, x3, p2, p3, [128, 128], False, None, scope='fa1', params=store)
+        f1 = PU.pointnet_fp_module(x1, x2, p1, f2, [128], False, None, scope='fa2', params=store)
+    finally:
+        PU.FUSED = True
+    L = lambda name: tuple(npy(t) for t in store[name])
+    # oracle composition (SSG channel order [xyz, features], pointnet_util.py:49; group_all un-centred, :77)
+    ox1 = O.gather_point(xyz, O.farthest_point_sample(128, xyz))
+    i1, _ = O.query_ball_point(0.2, 64, xyz, ox1)
+    assert np.array_equal(npy(idx1), i1)
+    g = O.group_point(xyz, i1) - ox1[:, :, None, :]
+    for j in range(3):
+        g = O.mlp_layer(g, *L('ssg-layer1/conv%d' % j))
+    op1 = O.max_pool(g, 64)
+    ox2 = O.gather_point(ox1, O.farthest_point_sample(32, ox1))
+    i2, _ = O.query_ball_point(0.4, 64, ox1, ox2)
+    g = np.concatenate([O.group_point(ox1, i2) - ox2[:, :, None, :], O.group_point(op1, i2)], -1)
+    for j in range(3):
+        g = O.mlp_layer(g, *L('ssg-layer2/conv%d' % j))
+    op2 = O.max_pool(g, 64)
+    g = np.concatenate([ox2, op2], -1)[:, None]
+    for j in range(3):
+        g = O.mlp_layer(g, *L('ssg-layer3/conv%d' % j))
+    op3 = O.max_pool(g, 32)
+    ox3 = np.zeros((4, 1, 3), np.float32)
+    assert np.array_equal(npy(x1), ox1) and np.array_equal(npy(x2), ox2) and np.array_equal(npy(x3), ox3)
+    close(npy(p1), op1, 0); close(npy(p2), op2, 0); close(npy(p3), op3, 0)
+    d, i3 = O.three_nn(ox2, ox3)                                  # m = 1 (frustum_pointnets_v2.py:228)
+    h = np.concatenate([O.three_interpolate(op3, i3, O.fp_weights(d)), op2], -1)
+    for j in range(2):
+        h = O.mlp_layer(h, *L('fa1/conv_%d' % j))
+    close(npy(f2), h, 0)
+    d, i3 = O.three_nn(ox1, ox2)
+    h2 = np.concatenate([O.three_interpolate(h, i3, O.fp_weights(d)), op1], -1)
+    h2 = O.mlp_layer(h2, *L('fa2/conv_0'))
+    close(npy(f1), h2, 0)
+
+
+def test_rpn_stack_runs_and_fused_equals_unfused(cuda):
+    pc = dev(S.kitti_batch(40, 1), cuda)
+    store = PU.ParamStore(seed=7, device=cuda)
+    out, aux = stacks.rpn_sa_fp_stack(pc, params=store)
+    assert out.shape == (1, 16384, 128)
+    assert [x.shape[1] for x in aux["xyz"]] == [16384, 4096, 1024, 256, 64]
+    assert [f.shape[2] for f in aux["sa_feats"][1:]] == [96, 256, 512, 1024]
+    PU.FUSED = False
+    try:
+        out2, _ = stacks.rpn_sa_fp_stack(pc, params=store)
+    finally:
+        PU.FUSED = True
+    close(npy(out), npy(out2), ops.PRECISION_FP32)
+    out3, _ = stacks.rpn_sa_fp_stack(pc, params=store, precision=ops.PRECISION_BF16)
+    ref = npy(out2)
+    assert float(np.abs(npy(out3) - ref).max()) <= 5e-2 * float(np.abs(ref).max())   # 8 layers deep in bf16
+
+
+def test_frustum_stacks_run(cuda):
+    store = PU.ParamStore(seed=9, device=cuda)
+    fr = dev(S.frustum_batch(1, 32, 1024), cuda)
+    assert stacks.frustum_cls_stack(fr, params=store).shape == (32, 512)
+    onehot = torch.zeros((32, 4), device=cuda); onehot[:, 1] = 1
+    assert stacks.frustum_seg_stack(fr, onehot, params=store).shape == (32, 1024, 128)
+    obj = dev(S.frustum_batch(2, 32, 512, channels=3), cuda)
+    assert stacks.frustum_box_stack(obj, params=store).shape == (32, 512)

@@ -1,0 +1,73 @@
+"""GPU parity: rotated NMS through the C ABI vs the float64 oracle
+(identical keep list except for pairs within 1e-5 of the IoU threshold)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from pointrcnn_amd import synthetic as S
+from pointrcnn_amd.nms_rotate import nms_rotate, nms_rotate_cpu
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(boxes, scores, thr, mx):
+    got = nms_rotate_cpu(boxes, scores, thr, mx)
+    want, margin = O.nms_rotate_cpu(boxes, scores, thr, mx, return_margin=True)
+    assert got.dtype == np.int64
+    if not np.array_equal(got, want):
+        assert margin < 1e-5, "keep lists differ although no pair is within 1e-5 of the threshold"
+    return got, want
+
+
+def test_reference_demo(cuda):
+    boxes = np.array([[50, 40, 100, 100, 0], [60, 50, 100, 100, 0],
+                      [50, 30, 100, 100, -45.], [200, 190, 100, 100, 0.]])
+    scores = np.array([0.99, 0.88, 0.66, 0.77])
+    assert list(nms_rotate_cpu(boxes, scores, 0.7, 1)) == [0]
+    assert list(nms_rotate_cpu(boxes, scores, 0.7, 10)) == [0, 1, 3, 2]
+    assert list(nms_rotate_cpu(boxes, scores, 0.68, 10)) == [0, 3, 2]
+    k = nms_rotate(torch.tensor(boxes, device=cuda), torch.tensor(scores, device=cuda), 0.7, 1)
+    assert k.dtype == torch.int64 and k.tolist() == [0]
+
+
+def test_edge_cases(cuda):
+    b = np.array([[0, 0, 5, 20, 0.], [0, 0, 5, 20, 0.], [0, 0, 5, 20, 180.], [0, 0, 20, 5, 90.],
+                  [0, 0, 1, 1, 10.], [100, 0, 5, 20, 0.], [102.5, 0, 5, 20, 0.], [0, 20, 5, 20, 0.]])
+    s = np.array([.9, .8, .7, .6, .5, .4, .3, .2])
+    for thr in (0.99, 0.5, 0.3, 0.009, 1e-9):
+        for mx in (1, 3, 100):
+            g, w = _check(b, s, thr, mx)
+            assert np.array_equal(g, w)
+    # identical / wrapped boxes are suppressed, the contained small box and the touching box survive
+    assert list(nms_rotate_cpu(b, s, 0.5, 100)) == [0, 4, 5, 6, 7]
+    assert len(nms_rotate_cpu(b[:0], s[:0], 0.5, 10)) == 0
+    assert len(nms_rotate_cpu(b, s, 0.5, 0)) == 0
+    assert list(nms_rotate_cpu(b, s, 0.0, 100)) == [0]         # iou >= 0 always: everything after the first goes
+
+
+@pytest.mark.parametrize("N,thr,mx", [(2048, 0.85, 300), (2048, 0.8, 100), (2048, 0.7, 10), (2048, 0.7, 300),
+                                      (777, 0.3, 1000), (130, 0.5, 64)])
+def test_reference_scale(cuda, N, thr, mx):
+    boxes, scores = S.nms_boxes(seed=N, N=N, clusters=max(2, N // 60))
+    got, want = _check(boxes, scores, thr, mx)
+    assert np.array_equal(got, want)
+
+
+def test_headline_9000_to_100(cuda):
+    boxes, scores = S.nms_boxes(seed=9000, N=9000)
+    got, want = _check(boxes, scores, 0.8, 100)
+    assert np.array_equal(got, want) and len(got) == 100
+    got, want = _check(boxes, scores, 0.3, 9000)               # deep sweep: most boxes suppressed
+    assert np.array_equal(got, want)
+    # idempotence: NMS of the kept set keeps everything
+    again = nms_rotate_cpu(boxes[got], scores[got], 0.3, 9000)
+    assert np.array_equal(again, np.arange(len(got)))
+
+
+def test_score_ties_resolve_to_lower_index(cuda):
+    boxes, _ = S.nms_boxes(seed=3, N=200, clusters=4)
+    scores = np.repeat(np.linspace(1, 0, 50), 4)
+    order = np.lexsort((np.arange(200), -scores))               # score desc, index asc
+    want = O.nms_rotate_cpu(boxes, scores, 0.5, 100, order=order)
+    assert np.array_equal(nms_rotate_cpu(boxes, scores, 0.5, 100), want)

@@ -1,0 +1,207 @@
+"""GPU parity tests: every primitive op through the C ABI vs the CPU oracle.
+
+Bar (BASELINE.json north_star): FPS / ball-query / grouping / three_nn indices bit-exact;
+gather / group / interpolate values bit-exact here too (the kernels use the reference's
+unfused fp32 expressions); fused-interpolation features within 1e-5 relative.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from pointrcnn_amd import ops, synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, cuda):
+    return torch.as_tensor(a).to(cuda)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+# ---- FPS ------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n,m", [(100, 100), (256, 64), (512, 128), (700, 90), (1024, 256),
+                                 (1500, 400), (3000, 300), (4096, 1024), (6000, 200), (16384, 512)])
+def test_fps_bit_exact_sizes(cuda, n, m):
+    pts = S.kitti_scene(1000 + n, n, max(64, int(n * 1.15)))[None, :, :3]
+    pts = np.concatenate([pts, S.kitti_scene(2000 + n, n, max(64, n // 3))[None, :, :3]], 0)  # heavy duplicates
+    got = npy(ops.farthest_point_sample(m, dev(pts, cuda)))
+    assert got.dtype == np.int32
+    assert np.array_equal(got, O.farthest_point_sample(m, pts))
+
+
+def test_fps_golden_tiebreak_and_duplicates(cuda, golden_dir):
+    g = np.load(os.path.join(golden_dir, "fps_transcription.npz"))
+    assert np.array_equal(npy(ops.farthest_point_sample(400, dev(g["cloud"], cuda))), g["idx_dup"])
+    assert np.array_equal(npy(ops.farthest_point_sample(4, dev(g["tie"], cuda))), g["idx_tie"])
+    assert np.array_equal(npy(ops.farthest_point_sample(100, dev(g["small"], cuda))), g["idx_small"])
+
+
+def test_fps_full_rpn_level1(cuda):
+    """16384 -> 4096 on a KITTI-shaped scene (BASELINE config 1, level 1)."""
+    pts = S.kitti_batch(0, 2)[:, :, :3]
+    got = npy(ops.farthest_point_sample(4096, dev(pts, cuda)))
+    assert np.array_equal(got, O.farthest_point_sample(4096, pts))
+
+
+def test_fps_lds_and_global_paths(cuda):
+    """n in (16384, 32768] keeps the min-distance array in LDS; n > 32768 uses `temp`."""
+    for n, m in ((20000, 300), (32768, 200), (40000, 150), (131072, 64)):
+        pts = S.dense_scene(7, n)[None, :, :3]
+        got = npy(ops.farthest_point_sample(m, dev(pts, cuda)))
+        assert np.array_equal(got, O.farthest_point_sample(m, pts)), n
+    # size-independent properties at full size: starts at 0, indices in range and unique
+    pts = S.dense_scene(8, 131072)[None, :, :3]
+    got = npy(ops.farthest_point_sample(2048, dev(pts, cuda)))[0]
+    assert got[0] == 0 and got.min() >= 0 and got.max() < 131072 and len(set(got.tolist())) == 2048
+
+
+def test_fps_errors(cuda):
+    x = torch.zeros((1, 8, 3), device=cuda)
+    with pytest.raises(ValueError):
+        ops.farthest_point_sample(0, x)
+    with pytest.raises(ValueError):
+        ops.farthest_point_sample(4, torch.zeros((1, 8, 4), device=cuda))
+    with pytest.raises(RuntimeError):
+        ops.farthest_point_sample(4, torch.zeros((1, 8, 3)))          # CPU tensor: no fallback
+    assert ops.farthest_point_sample(4, torch.zeros((0, 8, 3), device=cuda)).shape == (0, 4)
+
+
+def test_gather_point(cuda):
+    rng = np.random.default_rng(0)
+    inp = rng.standard_normal((3, 777, 3)).astype(np.float32)
+    idx = rng.integers(0, 777, (3, 300)).astype(np.int32)
+    assert np.array_equal(npy(ops.gather_point(dev(inp, cuda), dev(idx, cuda))), O.gather_point(inp, idx))
+
+
+# ---- ball query / group ------------------------------------------------------------------
+
+def test_query_ball_golden(cuda, golden_dir):
+    g = np.load(os.path.join(golden_dir, "grouping_ref.npz"))
+    ns = int(g["nsample"])
+    for r, key in ((0.05, "idx_r0p05"), (0.15, "idx_r0p15"), (0.4, "idx_r0p4")):
+        idx, cnt = ops.query_ball_point(r, ns, dev(g["xyz1"], cuda), dev(g["xyz2"], cuda))
+        assert np.array_equal(npy(idx), g[key])
+    e = np.load(os.path.join(golden_dir, "ballquery_edge_ref.npz"))
+    for r, key in ((0.5, "idx_r0p5"), (5.0, "idx_r5"),
+                   (float(np.nextafter(np.float32(5), np.float32(6))), "idx_r5p0001")):
+        idx, _ = ops.query_ball_point(r, 4, dev(e["xyz1"], cuda), dev(e["xyz2"], cuda))
+        assert np.array_equal(npy(idx), e[key])
+
+
+@pytest.mark.parametrize("n,m,r,ns", [(16384, 4096, 0.1, 16), (16384, 4096, 0.5, 32), (4096, 1024, 1.0, 32),
+                                      (1024, 256, 2.0, 32), (256, 64, 4.0, 32), (1000, 77, 0.3, 128),
+                                      (300, 5, 0.7, 64)])
+def test_query_ball_rpn_levels(cuda, n, m, r, ns):
+    pts = S.kitti_batch(3, 2, n)[:, :, :3]
+    fi = O.farthest_point_sample(m, pts)
+    cen = O.gather_point(pts, fi)
+    idx, cnt = ops.query_ball_point(r, ns, dev(pts, cuda), dev(cen, cuda))
+    oi, oc = O.query_ball_point(r, ns, pts, cen)
+    assert np.array_equal(npy(idx), oi)
+    assert np.array_equal(npy(cnt), oc)
+    assert oc.min() >= 1                      # centroids are points: d clamps to 1e-20 < r
+
+
+def test_query_ball_no_hit_rows_and_far_queries(cuda):
+    pts = np.random.default_rng(1).random((1, 500, 3), dtype=np.float32)
+    q = np.float32([[[10, 10, 10], [0.5, 0.5, 0.5]]])
+    idx, cnt = ops.query_ball_point(0.2, 8, dev(pts, cuda), dev(q, cuda))
+    oi, oc = O.query_ball_point(0.2, 8, pts, q)
+    assert np.array_equal(npy(cnt), oc) and oc[0, 0] == 0
+    assert np.array_equal(npy(idx), oi)       # untouched row reads 0 in both (zero-initialised)
+
+
+def test_query_ball_frustum_shapes(cuda):
+    fr = S.frustum_batch(5, 32, 1024)[:, :, :3]
+    fi = O.farthest_point_sample(128, fr)
+    cen = O.gather_point(fr, fi)
+    for r, ns in ((0.2, 32), (0.4, 64), (0.8, 128)):
+        idx, cnt = ops.query_ball_point(r, ns, dev(fr, cuda), dev(cen, cuda))
+        oi, oc = O.query_ball_point(r, ns, fr, cen)
+        assert np.array_equal(npy(idx), oi) and np.array_equal(npy(cnt), oc)
+
+
+def test_query_ball_errors(cuda):
+    x = torch.zeros((1, 8, 3), device=cuda)
+    with pytest.raises(ValueError):
+        ops.query_ball_point(0.0, 4, x, x)
+    with pytest.raises(ValueError):
+        ops.query_ball_point(0.5, 0, x, x)
+    with pytest.raises(ValueError):
+        ops.query_ball_point(0.5, 4, x, torch.zeros((2, 8, 3), device=cuda))
+
+
+@pytest.mark.parametrize("c", [1, 3, 4, 7, 96, 99, 256])
+def test_group_point(cuda, c, golden_dir):
+    rng = np.random.default_rng(c)
+    pts = rng.standard_normal((2, 900, c)).astype(np.float32)
+    idx = rng.integers(0, 900, (2, 130, 16)).astype(np.int32)
+    idx[0, 0, :] = 5                                           # repeated indices
+    got = npy(ops.group_point(dev(pts, cuda), dev(idx, cuda)))
+    assert np.array_equal(got, O.group_point(pts, idx))
+    if c == 7:
+        g = np.load(os.path.join(golden_dir, "grouping_ref.npz"))
+        got = npy(ops.group_point(dev(g["points"], cuda), dev(g["idx_r0p15"], cuda)))
+        assert np.array_equal(got, g["grouped_r0p15"])
+
+
+# ---- three_nn / interpolate --------------------------------------------------------------
+
+@pytest.mark.parametrize("n,m", [(256, 64), (1024, 256), (4096, 1024), (16384, 4096), (32, 1), (128, 2),
+                                 (128, 32), (1000, 3), (5000, 2500)])
+def test_three_nn_bit_exact(cuda, n, m):
+    pts = S.kitti_batch(7, 2, max(n, m))[:, :, :3]
+    a = pts[:, :n]
+    k = O.gather_point(pts, O.farthest_point_sample(m, pts))   # known points are a subset: exact zeros
+    d, i = ops.three_nn(dev(a, cuda), dev(k, cuda))
+    od, oi = O.three_nn(a, k)
+    assert np.array_equal(npy(i), oi)
+    assert np.array_equal(npy(d), od)                          # includes +inf slots when m < 3
+    w = ops.fp_weights(d)
+    assert np.array_equal(npy(w), O.fp_weights(od))
+
+
+def test_three_nn_golden_origin(cuda, golden_dir):
+    g = np.load(os.path.join(golden_dir, "threenn_origin_ref.npz"))
+    d, i = ops.three_nn(torch.zeros((3, 5, 3), device=cuda), dev(g["xyz2"], cuda))
+    assert np.array_equal(npy(d), g["dist"]) and np.array_equal(npy(i), g["idx"])
+
+
+@pytest.mark.parametrize("c", [1, 5, 20, 128, 516, 1028])
+def test_three_interpolate_bit_exact(cuda, c, golden_dir):
+    rng = np.random.default_rng(c)
+    pts = rng.standard_normal((2, 64, c)).astype(np.float32)
+    idx = rng.integers(0, 64, (2, 500, 3)).astype(np.int32)
+    w = rng.random((2, 500, 3), dtype=np.float32)
+    got = npy(ops.three_interpolate(dev(pts, cuda), dev(idx, cuda), dev(w, cuda)))
+    assert np.array_equal(got, O.three_interpolate(pts, idx, w))
+    if c == 20:
+        g = np.load(os.path.join(golden_dir, "interpolate_ref.npz"))
+        got = npy(ops.three_interpolate(dev(g["points"], cuda), dev(g["idx"], cuda), dev(g["weight"], cuda)))
+        assert np.array_equal(got, g["out"])
+
+
+@pytest.mark.parametrize("n,m,c,extra", [(256, 64, 1024, 512), (1024, 256, 512, 256), (4096, 1024, 512, 96),
+                                         (32, 1, 1028, 0), (300, 7, 9, 2), (16384, 4096, 256, 4)])
+def test_fused_three_nn_interpolate(cuda, n, m, c, extra):
+    pts = S.kitti_batch(11, 2, max(n, m))[:, :, :3]
+    a = pts[:, :n]
+    k = O.gather_point(pts, O.farthest_point_sample(m, pts))
+    feat = np.random.default_rng(c).standard_normal((2, m, c)).astype(np.float32)
+    buf = torch.full((2, n, c + extra), -7.0, device=cuda)
+    out, d, i = ops.three_nn_interpolate(dev(a, cuda), dev(k, cuda), dev(feat, cuda), out=buf, return_nn=True)
+    od, oi = O.three_nn(a, k)
+    ref = O.three_interpolate(feat, oi, O.fp_weights(od))
+    assert np.array_equal(npy(i), oi) and np.array_equal(npy(d), od)
+    got = npy(buf)
+    # tolerance of the north_star for interpolated features: 1e-5 relative
+    assert np.allclose(got[:, :, :c], ref, rtol=1e-5, atol=1e-6)
+    assert np.array_equal(got[:, :, :c], ref)                  # and in fact bit-exact
+    assert (got[:, :, c:] == -7.0).all()                       # the rest of the concat buffer is untouched

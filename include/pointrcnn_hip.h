@@ -44,6 +44,8 @@ typedef enum {
 
 const char *prcnn_status_string(int status);
 int prcnn_version(void);
+/* Text of the last HIP error seen by the calling thread (diagnostics for PRCNN_HIP_ERROR). */
+const char *prcnn_last_hip_error_string(void);
 
 /* ---- sampling ---------------------------------------------------------------------- */
 

@@ -6,6 +6,12 @@ object is missing, `lib()` raises and every op fails loudly.
 import ctypes
 import os
 
+# torch must be imported BEFORE the library is loaded: torch bundles its own HIP runtime
+# (SONAME libamdhip64.so.7), and the dynamic loader resolves our NEEDED entry to that
+# already-loaded copy.  Loaded the other way round, the process would hold two HIP/HSA
+# runtimes and the second one finds no device.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpointrcnn_hip.so")
 
@@ -16,6 +22,7 @@ _vp, _i, _f, _d, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_double, _c.
 SIGNATURES = {
     "prcnn_status_string": (_c.c_char_p, [_i]),
     "prcnn_version": (_i, []),
+    "prcnn_last_hip_error_string": (_c.c_char_p, []),
     "prcnn_farthest_point_sample": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "prcnn_fps_temp_bytes": (_sz, [_i, _i]),
     "prcnn_gather_point": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -64,4 +71,6 @@ def check(status, what):
     msg = lib().prcnn_status_string(status).decode()
     if status in (-1, -2):
         raise ValueError("%s: %s" % (what, msg))
+    if status == -3:
+        msg += " [%s]" % lib().prcnn_last_hip_error_string().decode()
     raise PointRCNNHipError("%s: %s" % (what, msg))

@@ -16,3 +16,11 @@ extern "C" const char *prcnn_status_string(int status)
 }
 
 extern "C" int prcnn_version(void) { return 100; }
+
+static thread_local int g_last_hip_error = 0;
+void prcnn_note_hip_error(int hip_status) { g_last_hip_error = hip_status; }
+
+extern "C" const char *prcnn_last_hip_error_string(void)
+{
+    return hipGetErrorString((hipError_t)g_last_hip_error);
+}

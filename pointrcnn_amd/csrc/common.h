@@ -4,9 +4,16 @@
 #include <stdint.h>
 #include "../../include/pointrcnn_hip.h"
 
+// The last failing HIP status of the calling thread is kept for diagnostics only
+// (prcnn_last_hip_error_string); it never influences a later call.
+void prcnn_note_hip_error(int hip_status);
 #define PRCNN_LAUNCH_CHECK()                                   \
     do {                                                       \
-        if (hipGetLastError() != hipSuccess) return PRCNN_HIP_ERROR; \
+        hipError_t e__ = hipGetLastError();                    \
+        if (e__ != hipSuccess) {                               \
+            prcnn_note_hip_error((int)e__);                    \
+            return PRCNN_HIP_ERROR;                            \
+        }                                                      \
     } while (0)
 
 static inline hipStream_t to_stream(prcnn_stream_t s) { return (hipStream_t)s; }

@@ -147,26 +147,35 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_kernel(const MlpArgs a)
     const bool b_vec = (a.cout & 3) == 0 && (((uintptr_t)a.w) & 15) == 0;
 
     f32x4 areg[A_PER / 4];
-    f32x4 breg[(B_PER + 3) / 4];
+    float breg[B_PER];
 
     auto load_chunk = [&](int k0) {
 #pragma unroll
         for (int v = 0; v < A_PER / 4; ++v)
             areg[v] = load_a4<GATHER>(a, rs, k0 + ahalf * A_PER + v * 4, a_vec);
         const int k = k0 + bk;
+        const bool kok = k < a.cin;
+        const float *wrow = a.w + (size_t)(kok ? k : 0) * a.cout;
+        if constexpr (B_PER >= 4) {
 #pragma unroll
-        for (int v = 0; v < (B_PER + 3) / 4; ++v) {
-            f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            const int n = col0 + bn + v * 4;
-            if (k < a.cin) {
-                const float *wp = a.w + (size_t)k * a.cout + n;
-                if (b_vec && B_PER >= 4 && n + 4 <= a.cout) t = *reinterpret_cast<const f32x4 *>(wp);
-                else {
+            for (int v = 0; v < B_PER / 4; ++v) {
+                const int n = col0 + bn + v * 4;
+                if (kok && b_vec && n + 4 <= a.cout) {
+                    const f32x4 t = *reinterpret_cast<const f32x4 *>(wrow + n);
+                    breg[v * 4 + 0] = t[0]; breg[v * 4 + 1] = t[1];
+                    breg[v * 4 + 2] = t[2]; breg[v * 4 + 3] = t[3];
+                } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (n + e < a.cout && v * 4 + e < B_PER) t[e] = wp[e];
+                    for (int e = 0; e < 4; ++e)
+                        breg[v * 4 + e] = (kok && n + e < a.cout) ? wrow[n + e] : 0.f;
                 }
             }
-            breg[v] = t;
+        } else {
+#pragma unroll
+            for (int e = 0; e < B_PER; ++e) {
+                const int n = col0 + bn + e;
+                breg[e] = (kok && n < a.cout) ? wrow[n] : 0.f;
+            }
         }
     };
     auto store_chunk = [&]() {
@@ -175,13 +184,8 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_kernel(const MlpArgs a)
             for (int v = 0; v < A_PER / 4; ++v)
                 *reinterpret_cast<f32x4 *>(&As[arow * AS + ahalf * A_PER + v * 4]) = areg[v];
 #pragma unroll
-            for (int v = 0; v < (B_PER + 3) / 4; ++v) {
-                if (B_PER >= 4) *reinterpret_cast<f32x4 *>(&Bs[bk * BN + bn + v * 4]) = breg[v];
-                else {
-#pragma unroll
-                    for (int e = 0; e < B_PER; ++e) Bs[bk * BN + bn + e] = __builtin_bit_cast(unsigned, breg[v][e]);
-                }
-            }
+            for (int e = 0; e < B_PER; ++e)
+                Bs[bk * BN + bn + e] = __builtin_bit_cast(unsigned, breg[e]);
         } else {
             // A: 16 bf16 per thread = 8 words at As[arow][ahalf*8 ..]
 #pragma unroll
@@ -192,12 +196,8 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_kernel(const MlpArgs a)
             // B transposed: element (k=bk, n) -> half-word bk of row n
             unsigned short *Bh = reinterpret_cast<unsigned short *>(Bs);
 #pragma unroll
-            for (int v = 0; v < (B_PER + 3) / 4; ++v)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (v * 4 + e < B_PER)
-                        Bh[(bn + v * 4 + e) * (AS * 2) + bk] =
-                            (unsigned short)(pack_bf16x2(breg[v][e], 0.f) & 0xffffu);
+            for (int e = 0; e < B_PER; ++e)
+                Bh[(bn + e) * (AS * 2) + bk] = (unsigned short)(pack_bf16x2(breg[e], 0.f) & 0xffffu);
         }
     };
 

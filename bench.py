@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Benchmark of the PointRCNN point-cloud hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: launched by torch.distributed.run, one rank per GPU over RCCL.)
+
+Workload (BASELINE.json configs[2], the config the metric "SA/FP-stack scenes/sec
+(16k pts)" is quoted on): the PointRCNN RPN SA+FP stack on a batch of 16 synthetic
+KITTI-shaped scenes x 16384 points per GPU, fused group->shared-MLP->max-pool on the
+matrix cores, followed by the rotated BEV NMS of each scene's 2048 proposals (top 100,
+IoU 0.8: the reference's val/test setting) and -- for N>1 -- ONE all-gather of the
+per-scene detection records.  One "step" = one such batch per rank (weak scaling: every
+rank processes its own 16 scenes per step).  Inputs are resident in HBM before the timed
+region.  Steps are issued round-robin on a few HIP streams so that the strictly serial
+farthest-point-sampling chain of one batch overlaps the matrix work of its neighbours.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant roofline-bound
+kernel, durations measured with HIP events inside the timed region), `kernels` (every
+kernel family), `fps` (the latency-bound sampler: us/iteration), `nms` (ms @ 9000 boxes),
+`cpu_baseline` (the CPU oracle = reference CPU path, 1 core, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from pointrcnn_amd import dist as pdist
+from pointrcnn_amd import ops, pointnet_util as PU, roofline, stacks, synthetic as S
+from pointrcnn_amd.nms_rotate import nms_rotate_batched, nms_rotate_padded
+
+BATCH = 16
+NPTS = 16384
+NPROP = 2048          # NUM_FG_POINT proposals per frame (models/model_util.py:16)
+
+
+def make_inputs(rank, device, batch):
+    pcs = torch.as_tensor(S.kitti_batch(rank * batch, batch, NPTS)).to(device)
+    boxes, scores, boxes3d = [], [], []
+    for i in range(batch):
+        b, s = S.nms_boxes(seed=7000 + rank * batch + i, N=NPROP, clusters=40)
+        boxes.append(b); scores.append(s)
+        b3 = np.stack([b[:, 0], np.full(NPROP, 1.0), b[:, 1], b[:, 2], np.full(NPROP, 1.5), b[:, 3],
+                       np.deg2rad(b[:, 4])], 1)
+        boxes3d.append(b3)
+    prop = {
+        "bev": torch.as_tensor(np.stack(boxes)).to(device),            # (B,N,5) f64
+        "scores": torch.as_tensor(np.stack(scores)).to(device),        # (B,N) f64
+        "boxes3d": torch.as_tensor(np.stack(boxes3d)).to(device),      # (B,N,7) f64
+        "scene_ids": torch.arange(rank * batch, (rank + 1) * batch, dtype=torch.float32, device=device),
+    }
+    return pcs, prop
+
+
+def step(pcs, prop, store, precision):
+    """SA+FP stack on the batch, per-scene rotated NMS of its proposals, detection records."""
+    feats, _ = stacks.rpn_sa_fp_stack(pcs, params=store, precision=precision)
+    keep, nk = nms_rotate_batched(prop["bev"], prop["scores"], 0.8, pdist.MAX_DET)
+    rec = pdist.pack_detections(prop["scene_ids"], prop["boxes3d"], prop["scores"], keep, nk)
+    return feats, rec
+
+
+def time_nms(device, n=9000, iters=20):
+    boxes, scores = S.nms_boxes(seed=9000, N=n)
+    b = torch.as_tensor(boxes).to(device); s = torch.as_tensor(scores).to(device)
+    for _ in range(3):
+        nms_rotate_padded(b, s, 0.8, 100)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        k, nk = nms_rotate_padded(b, s, 0.8, 100)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters, int(nk.item())
+
+
+def cpu_baseline(store, seconds_cap=40.0):
+    """The CPU oracle (reference CPU path: C++ CPU ops restated + transcribed FPS kernel)
+    on ONE 16384-point scene of the same generator, single thread."""
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:                                           # pragma: no cover
+        threadpool_limits = None
+    from oracle import oracle as O
+    from oracle import stack as ostack
+    O.lib()
+    params = {k: tuple(t.detach().cpu().numpy() for t in v) for k, v in store.items()}
+    timers = {}
+    nscenes, dt = 0, 0.0
+    while dt < 10.0 and nscenes < 16:                            # bounded sample: ~10-30 s of CPU work
+        pc = S.kitti_batch(nscenes, 1, NPTS)
+        t0 = time.perf_counter()
+        if threadpool_limits:
+            with threadpool_limits(limits=1):
+                ostack.rpn_sa_fp_stack(pc, params, gemm='blas', timers=timers)
+        else:
+            ostack.rpn_sa_fp_stack(pc, params, gemm='blas', timers=timers)
+        dt += time.perf_counter() - t0
+        nscenes += 1
+    dt /= nscenes
+    timers = {k: v / nscenes for k, v in timers.items()}
+    boxes, scores = S.nms_boxes(seed=7000, N=NPROP, clusters=40)
+    t1 = time.perf_counter()
+    O.nms_rotate_cpu(boxes, scores, 0.8, 100)
+    tn = time.perf_counter() - t1
+    b9, s9 = S.nms_boxes(seed=9000, N=9000)
+    t1 = time.perf_counter()
+    O.nms_rotate_cpu(b9, s9, 0.8, 100)
+    tn9 = time.perf_counter() - t1
+    return {"value": 1.0 / (dt + tn), "unit": "scenes/s", "cores": 1, "kind": "port",
+            "sample": "%d scenes x 16384 pts through the C oracle op by op (+ NumPy fp32 GEMM, 1 BLAS thread) "
+                      "+ rotated NMS 2048->100 each; %.2f s per scene" % (nscenes, dt + tn),
+            "seconds": {k: round(v, 4) for k, v in timers.items()},
+            "nms_ms_2048": tn * 1e3, "nms_ms_9000": tn9 * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--streams", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue every step eagerly instead of replaying HIP graphs")
+    args = ap.parse_args()
+
+    rank, world, local = pdist.init_from_env("cuda")
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    precision = ops.PRECISION_FP32 if args.precision == "f32" else ops.PRECISION_BF16
+    store = PU.ParamStore(seed=7, device=device)
+    pcs, prop = make_inputs(rank, device, args.batch)
+    streams = [torch.cuda.Stream(device=device) for _ in range(max(1, args.streams))]
+
+    # One HIP graph of the whole step per stream (the C ABI allocates nothing and never
+    # synchronises, so it captures as is); the all-gather stays outside the graph.
+    graphs, outs = [], []
+    if not args.no_graph:
+        for st in streams:
+            with torch.cuda.stream(st):
+                step(pcs, prop, store, precision)                  # lazy init + allocator warm-up
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                o = step(pcs, prop, store, precision)
+            graphs.append(g); outs.append(o)
+
+    def run_steps(k, timer=None):
+        prev = ops.set_timer(timer)
+        try:
+            for i in range(k):
+                j = i % len(streams)
+                with torch.cuda.stream(streams[j]):
+                    if graphs and timer is None:
+                        graphs[j].replay()
+                        rec = outs[j][1]
+                    else:
+                        rec = step(pcs, prop, store, precision)[1]
+                    pdist.all_gather_detections(rec)
+        finally:
+            ops.set_timer(prev)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_steps(args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    t_issue = time.perf_counter() - t0
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # Instrumented pass (eager, HIP events around every launch, same streams and steps):
+    # per-kernel durations for the roofline numbers.  Not part of `value`.
+    timer = ops.KernelTimer()
+    run_steps(min(args.steps, 6), timer)
+    fence()
+
+    if rank == 0:
+        scenes = args.batch * args.steps * world
+        ksum = timer.summary()
+        kernels = {}
+        for name, d in ksum.items():
+            e = {"launches": d["launches"], "ms_total": round(d["ms"], 3),
+                 "avg_us": round(1e3 * d["ms"] / d["launches"], 2)}
+            if "flops" in d:
+                peak = roofline.FP32_MFMA_PEAK_TFLOPS if precision == 0 else roofline.BF16_MFMA_PEAK_TFLOPS
+                e.update(bound="mfma", achieved=d["flops"] / (d["ms"] * 1e-3) / 1e12, peak=peak, unit="TFLOP/s")
+            elif name in ("group_point", "three_interpolate", "three_nn_interpolate", "gather_point"):
+                e.update(bound="hbm", achieved=d["bytes"] / (d["ms"] * 1e-3) / 1e9, peak=roofline.HBM_PEAK_GBS,
+                         unit="GB/s")
+            if "achieved" in e:
+                e["frac"] = e["achieved"] / e["peak"]
+                e["achieved"] = round(e["achieved"], 3); e["frac"] = round(e["frac"], 4)
+            if "tests" in d:
+                e["gtests_per_s"] = round(d["tests"] / (d["ms"] * 1e-3) / 1e9, 2)
+            kernels[name] = e
+        # dominant roofline-bound kernel family = the one with the most time among hbm/mfma ones
+        cand = [(v["ms_total"], k) for k, v in kernels.items() if "bound" in v]
+        dom = max(cand)[1] if cand else None
+        roof = None
+        if dom:
+            v = kernels[dom]
+            roof = {"kernel": dom, "bound": v["bound"], "achieved": v["achieved"], "peak": v["peak"],
+                    "unit": v["unit"], "frac": v["frac"], "traffic": None,
+                    "avg_launch_us": v["avg_us"], "launches": v["launches"]}
+        fps = None
+        if "fps" in ksum:
+            d = ksum["fps"]
+            # per launch all clouds of the batch run concurrently (one workgroup each)
+            fps = {"bound": "latency", "us_per_iteration": round(1e3 * d["ms"] / (d["iters"]), 4),
+                   "ms_total": round(d["ms"], 3), "launches": d["launches"],
+                   "gdist_evals_per_s": round(d["dist_evals"] / (d["ms"] * 1e-3) / 1e9, 2)}
+        nms_ms, nms_keep = time_nms(device)
+        out = {
+            "metric": "SA/FP-stack scenes/sec (16k pts)", "value": round(scenes / elapsed, 2), "unit": "scenes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "PointRCNN RPN SA+FP stack, batch %d x %d pts per GPU, fused group->shared-MLP"
+                                   "->max-pool (MFMA), + rotated NMS %d->100 per scene%s" %
+                                   (args.batch, NPTS, NPROP, " + RCCL all-gather of detections" if world > 1 else ""),
+                       "batch_per_gpu": args.batch, "points": NPTS, "streams": len(streams),
+                       "hip_graph": bool(graphs), "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3),
+                       "kernel_timing": "HIP events around every launch in an eager instrumented pass "
+                                        "of the same steps after the timed region",
+                       "parallelism": "scene-sharded x%d" % world},
+            "roofline": roof, "kernels": kernels, "fps": fps,
+            "nms": {"ms_9000_to_100": round(nms_ms, 4), "kept": nms_keep, "pairs": 9000 * 8999 // 2,
+                    "metric": "rotated-NMS ms @9k boxes"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(store)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

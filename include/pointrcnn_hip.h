@@ -129,6 +129,17 @@ int prcnn_nms_rotate(int n, const double *boxes, const double *scores, double io
                      int max_output_size, int64_t *keep, int *n_keep, void *workspace,
                      size_t workspace_bytes, prcnn_stream_t stream);
 
+/* The same NMS on `batch` independent box sets of equal size n in one set of launches
+ * (one frame per set: dataset/frustum_dataset.py:117-137 runs it once per frame; a batch
+ * of frames is what one GPU holds).  boxes (batch,n,5), scores (batch,n), keep
+ * (batch,max_output_size), n_keep (batch).  No counterpart in the reference beyond the
+ * per-frame loop; prcnn_nms_rotate is this call with batch = 1. */
+size_t prcnn_nms_rotate_batched_workspace_bytes(int batch, int n);
+int prcnn_nms_rotate_batched(int batch, int n, const double *boxes, const double *scores,
+                             double iou_threshold, int max_output_size, int64_t *keep,
+                             int *n_keep, void *workspace, size_t workspace_bytes,
+                             prcnn_stream_t stream);
+
 /* ---- shared MLP (1x1 conv + folded BN + ReLU) and pooling --------------------------- */
 
 /* One shared-MLP layer, models/tf_util.py:120-185 (conv2d 1x1 + bias + batch_norm +

@@ -5,8 +5,9 @@
 // Three launches on the caller's stream, float64 arithmetic throughout (MI355X runs
 // fp64 VALU at half the fp32 rate, and the reference's boxes/scores are float64):
 //   1. rank_kernel     counting sort: rank_i = #{j : s_j > s_i or (s_j == s_i and j < i)}
-//                      (scores tiled through LDS) and the per-box geometry record
-//                      written at its rank -> everything downstream is in score order.
+//                      (scores tiled through LDS, j range sliced over workgroups, integer
+//                      atomics) + finalize_rank_kernel: order[] and the per-box geometry
+//                      record written at its rank -> everything downstream is in score order.
 //   2. mask_kernel     all-pairs suppression bitmask, one wave per 64x64 block of the
 //                      upper triangle.  Each lane first screens its row against the 64
 //                      column boxes with a circumscribed-circle test, the surviving
@@ -34,40 +35,68 @@ struct BoxRec {            // 64 bytes, written at the box's rank
 constexpr int RANK_THREADS = 256;
 constexpr int RANK_TILE = 2048;
 
-__global__ __launch_bounds__(RANK_THREADS) void rank_kernel(int n, const double *__restrict__ boxes,
-                                                            const double *__restrict__ scores,
-                                                            int *__restrict__ order,
-                                                            BoxRec *__restrict__ rec)
+// Partial ranks: block (x = i-block, y = j-slice, z = scene) counts, for its 256 boxes i,
+// the boxes j of its slice that sort before i, and adds the count to rank[i] (zeroed by a
+// hipMemsetAsync ahead of the launch).  Integer atomics: the result is order-independent.
+__global__ __launch_bounds__(RANK_THREADS) void rank_kernel(int n, int slice,
+                                                            const double *__restrict__ scores_all,
+                                                            int *__restrict__ rank_all)
 {
-    __shared__ double ss[RANK_TILE];
+    __shared__ __attribute__((aligned(16))) double ss[RANK_TILE];
+    const double *scores = scores_all + (size_t)blockIdx.z * n;
+    int *rank = rank_all + (size_t)blockIdx.z * n;
     const int i = blockIdx.x * RANK_THREADS + threadIdx.x;
     const bool ok = i < n;
     const double si = ok ? scores[i] : 0.0;
-    int rank = 0;
-    for (int base = 0; base < n; base += RANK_TILE) {
-        const int tn = min(RANK_TILE, n - base);
+    const int j0 = blockIdx.y * slice;
+    const int j1 = min(n, j0 + slice);
+    int cnt = 0;
+    for (int base = j0; base < j1; base += RANK_TILE) {
+        const int tn = min(RANK_TILE, j1 - base);
         __syncthreads();
-        for (int k = threadIdx.x; k < tn; k += RANK_THREADS) ss[k] = scores[base + k];
+        for (int k = threadIdx.x; k < RANK_TILE; k += RANK_THREADS)
+            ss[k] = k < tn ? scores[base + k] : __builtin_nan("");   // NaN never sorts before i
         __syncthreads();
         if (ok) {
-            for (int k = 0; k < tn; ++k) {
-                const double sj = ss[k];
-                rank += (sj > si || (sj == si && base + k < i)) ? 1 : 0;
+            // j < i only matters for equal scores; split the tile at i to keep the loop branch-free
+            const int tn4 = (tn + 3) & ~3;
+            int c = 0;
+#pragma unroll 2
+            for (int k = 0; k < tn4; k += 4) {
+                const double2 a = *reinterpret_cast<const double2 *>(&ss[k]);
+                const double2 b = *reinterpret_cast<const double2 *>(&ss[k + 2]);
+                const int g = base + k;
+                c += (a.x > si || (a.x == si && g < i)) ? 1 : 0;
+                c += (a.y > si || (a.y == si && g + 1 < i)) ? 1 : 0;
+                c += (b.x > si || (b.x == si && g + 2 < i)) ? 1 : 0;
+                c += (b.y > si || (b.y == si && g + 3 < i)) ? 1 : 0;
             }
+            cnt += c;
         }
     }
-    if (ok) {
-        order[rank] = i;
-        const double *b = boxes + (size_t)i * 5;
-        const double ang = b[4] * 3.14159265358979323846 / 180.0;
-        BoxRec r;
-        r.u = b[1]; r.v = b[0];
-        sincos(ang, &r.s, &r.c);
-        r.hw = 0.5 * b[3]; r.hh = 0.5 * b[2];
-        r.area = b[2] * b[3];
-        r.rad = sqrt(r.hw * r.hw + r.hh * r.hh);
-        rec[rank] = r;
-    }
+    if (ok && cnt) atomicAdd(&rank[i], cnt);
+}
+
+// order[rank_i] = i and the geometry record of box i at its rank.
+__global__ __launch_bounds__(RANK_THREADS) void finalize_rank_kernel(int n, const double *__restrict__ boxes_all,
+                                                                     const int *__restrict__ rank_all,
+                                                                     int *__restrict__ order_all,
+                                                                     BoxRec *__restrict__ rec_all)
+{
+    const int i = blockIdx.x * RANK_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const size_t so = (size_t)blockIdx.z * n;
+    const int rank = rank_all[so + i];
+    order_all[so + rank] = i;
+    const double *b = boxes_all + (so + i) * 5;
+    const double ang = b[4] * 3.14159265358979323846 / 180.0;
+    BoxRec r;
+    r.u = b[1]; r.v = b[0];
+    sincos(ang, &r.s, &r.c);
+    r.hw = 0.5 * b[3]; r.hh = 0.5 * b[2];
+    r.area = b[2] * b[3];
+    r.rad = sqrt(r.hw * r.hw + r.hh * r.hh);
+    rec_all[so + rank] = r;
 }
 
 // Clip polygon (px,py)[0..cnt) against the half-plane  sgn*coord <= lim  where coord is x
@@ -129,9 +158,11 @@ __device__ double rect_intersection(const BoxRec &p, const BoxRec &q)
 
 // One wave per (row block, col block) of the upper triangle.
 __global__ __launch_bounds__(64) void mask_kernel(int n, int words, double thr,
-                                                  const BoxRec *__restrict__ rec,
-                                                  unsigned long long *__restrict__ mask)
+                                                  const BoxRec *__restrict__ rec_all,
+                                                  unsigned long long *__restrict__ mask_all)
 {
+    const BoxRec *rec = rec_all + (size_t)blockIdx.z * n;
+    unsigned long long *mask = mask_all + (size_t)blockIdx.z * n * words;
     __shared__ BoxRec colb[64];
     __shared__ unsigned long long bits[64];
     __shared__ unsigned short pairs[64 * 64];
@@ -201,8 +232,9 @@ __global__ __launch_bounds__(64) void mask_kernel(int n, int words, double thr,
 
 // thr <= 0 suppresses pairs with zero overlap too (0 >= thr): handled by a dense kernel.
 __global__ __launch_bounds__(64) void mask_all_kernel(int n, int words,
-                                                      unsigned long long *__restrict__ mask)
+                                                      unsigned long long *__restrict__ mask_all)
 {
+    unsigned long long *mask = mask_all + (size_t)blockIdx.z * n * words;
     const long long total = (long long)n * words;
     for (long long e = blockIdx.x * 64ll + threadIdx.x; e < total; e += gridDim.x * 64ll) {
         const int r = (int)(e / words), w = (int)(e - (long long)r * words);
@@ -220,12 +252,16 @@ __global__ __launch_bounds__(64) void mask_all_kernel(int n, int words,
 constexpr int SWEEP_MAX_WORDS = 8192;   // n <= 524288
 
 __global__ __launch_bounds__(64) void sweep_kernel(int n, int words, int max_out,
-                                                   const unsigned long long *__restrict__ mask,
-                                                   const int *__restrict__ order,
-                                                   long long *__restrict__ keep,
-                                                   int *__restrict__ n_keep)
+                                                   const unsigned long long *__restrict__ mask_all,
+                                                   const int *__restrict__ order_all,
+                                                   long long *__restrict__ keep_all,
+                                                   int *__restrict__ n_keep_all)
 {
     __shared__ unsigned long long removed[SWEEP_MAX_WORDS];
+    const unsigned long long *mask = mask_all + (size_t)blockIdx.x * n * words;
+    const int *order = order_all + (size_t)blockIdx.x * n;
+    long long *keep = keep_all + (size_t)blockIdx.x * max_out;
+    int *n_keep = n_keep_all + blockIdx.x;
     const int lane = threadIdx.x;
     for (int w = lane; w < words; w += 64) {
         // bits beyond n are "removed" so the scan never selects them
@@ -263,27 +299,90 @@ __global__ __launch_bounds__(64) void sweep_kernel(int n, int words, int max_out
 }
 
 struct NmsLayout {
-    size_t order_off, rec_off, mask_off, total;
+    size_t rank_off, order_off, rec_off, mask_off, total;
     int words;
 };
-static NmsLayout nms_layout(int n)
+static NmsLayout nms_layout(int batch, int n)
 {
     NmsLayout L;
     L.words = (n + 63) / 64;
+    const size_t B = (size_t)batch;
     size_t off = 0;
-    L.order_off = off; off += ((size_t)n * sizeof(int) + 255) & ~(size_t)255;
-    L.rec_off = off; off += ((size_t)n * sizeof(BoxRec) + 255) & ~(size_t)255;
-    L.mask_off = off; off += (size_t)n * L.words * sizeof(unsigned long long);
+    L.rank_off = off; off += (B * n * sizeof(int) + 255) & ~(size_t)255;
+    L.order_off = off; off += (B * n * sizeof(int) + 255) & ~(size_t)255;
+    L.rec_off = off; off += (B * n * sizeof(BoxRec) + 255) & ~(size_t)255;
+    L.mask_off = off; off += B * n * L.words * sizeof(unsigned long long);
     L.total = off + 256;
     return L;
 }
 
 }  // namespace prcnn
 
+extern "C" size_t prcnn_nms_rotate_batched_workspace_bytes(int batch, int n)
+{
+    if (n <= 0 || batch <= 0) return 256;
+    return prcnn::nms_layout(batch, n).total;
+}
+
 extern "C" size_t prcnn_nms_rotate_workspace_bytes(int n)
 {
-    if (n <= 0) return 256;
-    return prcnn::nms_layout(n).total;
+    return prcnn_nms_rotate_batched_workspace_bytes(1, n);
+}
+
+extern "C" int prcnn_nms_rotate_batched(int batch, int n, const double *boxes, const double *scores,
+                                        double iou_threshold, int max_output_size, int64_t *keep,
+                                        int *n_keep, void *workspace, size_t workspace_bytes,
+                                        prcnn_stream_t stream)
+{
+    using namespace prcnn;
+    if (n < 0 || batch < 0) return PRCNN_BAD_SHAPE;
+    if (batch == 0) return PRCNN_OK;
+    if (!n_keep) return PRCNN_BAD_SHAPE;
+    if (batch > 65535) return PRCNN_UNSUPPORTED;
+    hipStream_t st = to_stream(stream);
+    if (n == 0 || max_output_size <= 0) {
+        if (hipMemsetAsync(n_keep, 0, sizeof(int) * (size_t)batch, st) != hipSuccess) return PRCNN_HIP_ERROR;
+        return PRCNN_OK;
+    }
+    if (!boxes || !scores || !keep) return PRCNN_BAD_SHAPE;
+    const NmsLayout L = nms_layout(batch, n);
+    if (L.words > SWEEP_MAX_WORDS) return PRCNN_UNSUPPORTED;
+    if (!workspace || workspace_bytes < L.total) return PRCNN_WORKSPACE;
+    if (((uintptr_t)workspace & 255) != 0) return PRCNN_WORKSPACE;
+    char *ws = (char *)workspace;
+    int *rank = (int *)(ws + L.rank_off);
+    int *order = (int *)(ws + L.order_off);
+    BoxRec *rec = (BoxRec *)(ws + L.rec_off);
+    unsigned long long *mask = (unsigned long long *)(ws + L.mask_off);
+
+    if (hipMemsetAsync(rank, 0, sizeof(int) * (size_t)batch * n, st) != hipSuccess) return PRCNN_HIP_ERROR;
+    const int iblocks = (n + RANK_THREADS - 1) / RANK_THREADS;
+    // enough j-slices to put >= ~1024 workgroups on the chip, each at least one tile long
+    int slices = (1024 + iblocks * batch - 1) / (iblocks * batch);
+    const int max_slices = (n + 511) / 512;
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    const int slice = (((n + slices - 1) / slices) + 3) & ~3;
+    slices = (n + slice - 1) / slice;
+    hipLaunchKernelGGL(rank_kernel, dim3(iblocks, slices, batch), dim3(RANK_THREADS), 0, st, n, slice,
+                       scores, rank);
+    PRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(finalize_rank_kernel, dim3(iblocks, 1, batch), dim3(RANK_THREADS), 0, st, n, boxes,
+                       rank, order, rec);
+    PRCNN_LAUNCH_CHECK();
+    if (iou_threshold > 0.0) {
+        const long long nblk = (long long)L.words * (L.words + 1) / 2;
+        // only the upper triangle (incl. the diagonal blocks) is ever read by the sweep
+        hipLaunchKernelGGL(mask_kernel, dim3((unsigned)nblk, 1, batch), dim3(64), 0, st, n, L.words,
+                           iou_threshold, rec, mask);
+    } else {
+        hipLaunchKernelGGL(mask_all_kernel, dim3(2048, 1, batch), dim3(64), 0, st, n, L.words, mask);
+    }
+    PRCNN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sweep_kernel, dim3(batch), dim3(64), 0, st, n, L.words, max_output_size, mask,
+                       order, (long long *)keep, n_keep);
+    PRCNN_LAUNCH_CHECK();
+    return PRCNN_OK;
 }
 
 extern "C" int prcnn_nms_rotate(int n, const double *boxes, const double *scores,
@@ -291,39 +390,6 @@ extern "C" int prcnn_nms_rotate(int n, const double *boxes, const double *scores
                                 int *n_keep, void *workspace, size_t workspace_bytes,
                                 prcnn_stream_t stream)
 {
-    using namespace prcnn;
-    if (n < 0) return PRCNN_BAD_SHAPE;
-    if (!n_keep) return PRCNN_BAD_SHAPE;
-    hipStream_t st = to_stream(stream);
-    if (n == 0 || max_output_size <= 0) {
-        if (hipMemsetAsync(n_keep, 0, sizeof(int), st) != hipSuccess) return PRCNN_HIP_ERROR;
-        return PRCNN_OK;
-    }
-    if (!boxes || !scores || !keep) return PRCNN_BAD_SHAPE;
-    const NmsLayout L = nms_layout(n);
-    if (L.words > SWEEP_MAX_WORDS) return PRCNN_UNSUPPORTED;
-    if (!workspace || workspace_bytes < L.total) return PRCNN_WORKSPACE;
-    if (((uintptr_t)workspace & 255) != 0) return PRCNN_WORKSPACE;
-    char *ws = (char *)workspace;
-    int *order = (int *)(ws + L.order_off);
-    BoxRec *rec = (BoxRec *)(ws + L.rec_off);
-    unsigned long long *mask = (unsigned long long *)(ws + L.mask_off);
-
-    hipLaunchKernelGGL(rank_kernel, dim3((n + RANK_THREADS - 1) / RANK_THREADS), dim3(RANK_THREADS), 0,
-                       st, n, boxes, scores, order, rec);
-    PRCNN_LAUNCH_CHECK();
-    if (iou_threshold > 0.0) {
-        const long long nblk = (long long)L.words * (L.words + 1) / 2;
-        // lower-triangle words are never read by the sweep (it starts at found/64) except
-        // the diagonal block, which the kernel writes.
-        hipLaunchKernelGGL(mask_kernel, dim3((unsigned)nblk), dim3(64), 0, st, n, L.words,
-                           iou_threshold, rec, mask);
-    } else {
-        hipLaunchKernelGGL(mask_all_kernel, dim3(2048), dim3(64), 0, st, n, L.words, mask);
-    }
-    PRCNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sweep_kernel, dim3(1), dim3(64), 0, st, n, L.words, max_output_size, mask,
-                       order, (long long *)keep, n_keep);
-    PRCNN_LAUNCH_CHECK();
-    return PRCNN_OK;
+    return prcnn_nms_rotate_batched(1, n, boxes, scores, iou_threshold, max_output_size, keep, n_keep,
+                                    workspace, workspace_bytes, stream);
 }

@@ -13,12 +13,12 @@ import torch
 from . import _lib
 
 
-def _run(boxes, scores, iou_threshold, max_output_size):
+def _run(boxes, scores, iou_threshold, max_output_size, pad=False):
     n = boxes.shape[0]
     L = _lib.lib()
     dev = boxes.device
     max_output_size = int(max_output_size)
-    cap = max(min(n, max_output_size), 0)
+    cap = max(max_output_size if pad else min(n, max_output_size), 0)
     keep = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
     nk = torch.zeros(1, dtype=torch.int32, device=dev)
     wsb = L.prcnn_nms_rotate_workspace_bytes(n)
@@ -29,6 +29,40 @@ def _run(boxes, scores, iou_threshold, max_output_size):
                                   max_output_size, keep.data_ptr(), nk.data_ptr(),
                                   ws.data_ptr() + off, wsb, st), "nms_rotate")
     return keep, nk
+
+
+def nms_rotate_batched(boxes, scores, iou_threshold, max_output_size, workspace=None):
+    """One NMS per frame for a batch of frames in one set of launches, no host sync.
+    boxes (B,N,5) / scores (B,N) float64 GPU tensors -> keep (B,max_output_size) int64,
+    n_keep (B,) int32.  `workspace` (uint8 GPU tensor) may be passed to avoid allocation."""
+    if not (boxes.is_cuda and boxes.dtype == torch.float64 and boxes.is_contiguous() and boxes.dim() == 3
+            and boxes.shape[2] == 5 and scores.dtype == torch.float64 and scores.is_contiguous()
+            and scores.shape == boxes.shape[:2]):
+        raise ValueError("nms_rotate_batched expects contiguous float64 GPU tensors (B,N,5) and (B,N)")
+    B, n, _ = boxes.shape
+    L = _lib.lib()
+    max_output_size = int(max_output_size)
+    keep = torch.empty((B, max(max_output_size, 1)), dtype=torch.int64, device=boxes.device)
+    nk = torch.empty(B, dtype=torch.int32, device=boxes.device)
+    wsb = L.prcnn_nms_rotate_batched_workspace_bytes(B, n)
+    if workspace is None or workspace.numel() < wsb + 256:
+        workspace = torch.empty(wsb + 256, dtype=torch.uint8, device=boxes.device)
+    off = (-workspace.data_ptr()) % 256
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.prcnn_nms_rotate_batched(B, n, boxes.data_ptr(), scores.data_ptr(), float(iou_threshold),
+                                          max_output_size, keep.data_ptr(), nk.data_ptr(),
+                                          workspace.data_ptr() + off, wsb, st), "nms_rotate_batched")
+    return keep, nk
+
+
+def nms_rotate_padded(boxes, scores, iou_threshold, max_output_size):
+    """Asynchronous form for pipelines: float64 GPU tensors in, (keep (max_output_size,)
+    int64, n_keep (1,) int32) GPU tensors out, no host synchronisation.  Entries of keep
+    beyond n_keep are unspecified."""
+    if not (boxes.is_cuda and boxes.dtype == torch.float64 and boxes.is_contiguous()
+            and scores.dtype == torch.float64 and scores.is_contiguous()):
+        raise ValueError("nms_rotate_padded expects contiguous float64 GPU tensors")
+    return _run(boxes, scores, iou_threshold, max_output_size, pad=True)
 
 
 def nms_rotate_cpu(boxes, scores, iou_threshold, max_output_size):

@@ -17,6 +17,51 @@ PRECISION_FP32 = 0
 PRECISION_BF16 = 1
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launch stream (used by bench.py
+    to measure each kernel's duration inside the timed region).  Each record carries the
+    launch's ALGORITHMIC work (bytes / flops / tests, formulas of SURVEY.md 8d)."""
+
+    def __init__(self):
+        self.records = []
+
+    def run(self, name, work, call):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = call()
+        e.record()
+        self.records.append((name, work, s, e))
+        return rc
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, work, s, e in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0})
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            for k, v in work.items():
+                d[k] = d.get(k, 0) + v
+        return out
+
+
+_TIMER = None
+
+
+def set_timer(timer):
+    """Install (or with None remove) a KernelTimer; returns the previous one."""
+    global _TIMER
+    prev, _TIMER = _TIMER, timer
+    return prev
+
+
+def _run(name, work, call):
+    if _TIMER is None:
+        return call()
+    return _TIMER.run(name, work, call)
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -50,7 +95,9 @@ def farthest_point_sample(npoint, inp):
     L = _lib.lib()
     tb = L.prcnn_fps_temp_bytes(b, n)
     temp = torch.empty(tb // 4, dtype=torch.float32, device=inp.device) if tb else None
-    _lib.check(L.prcnn_farthest_point_sample(b, n, npoint, _p(inp), _p(temp), _p(out), _stream()),
+    _lib.check(_run("fps", {"iters": max(npoint - 1, 0), "dist_evals": b * max(npoint - 1, 0) * n,
+                             "bytes": b * (12 * n + 4 * npoint)},
+                    lambda: L.prcnn_farthest_point_sample(b, n, npoint, _p(inp), _p(temp), _p(out), _stream())),
                "FarthestPointSample")
     return out
 
@@ -64,7 +111,8 @@ def gather_point(inp, idx):
     b, n, _ = inp.shape
     m = idx.shape[1]
     out = torch.empty((b, m, 3), dtype=torch.float32, device=inp.device)
-    _lib.check(_lib.lib().prcnn_gather_point(b, n, m, _p(inp), _p(idx), _p(out), _stream()),
+    _lib.check(_run("gather_point", {"bytes": b * m * 28},
+                    lambda: _lib.lib().prcnn_gather_point(b, n, m, _p(inp), _p(idx), _p(out), _stream())),
                "GatherPoint")
     return out
 
@@ -84,8 +132,9 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     nsample = int(nsample)
     idx = torch.zeros((b, m, max(nsample, 0)), dtype=torch.int32, device=xyz1.device)
     cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
-    _lib.check(_lib.lib().prcnn_query_ball_point(b, n, m, float(radius), nsample, _p(xyz1), _p(xyz2),
-                                                 _p(idx), _p(cnt), _stream()), "QueryBallPoint")
+    _lib.check(_run("query_ball_point", {"tests": b * m * n, "bytes": b * (12 * n + 12 * m + 4 * m * nsample + 4 * m)},
+                    lambda: _lib.lib().prcnn_query_ball_point(b, n, m, float(radius), nsample, _p(xyz1), _p(xyz2),
+                                                              _p(idx), _p(cnt), _stream())), "QueryBallPoint")
     return idx, cnt
 
 
@@ -98,7 +147,8 @@ def group_point(points, idx):
     b, n, c = points.shape
     _, m, ns = idx.shape
     out = torch.empty((b, m, ns, c), dtype=torch.float32, device=points.device)
-    _lib.check(_lib.lib().prcnn_group_point(b, n, c, m, ns, _p(points), _p(idx), _p(out), _stream()),
+    _lib.check(_run("group_point", {"bytes": b * m * ns * (4 + 8 * c)},
+                    lambda: _lib.lib().prcnn_group_point(b, n, c, m, ns, _p(points), _p(idx), _p(out), _stream())),
                "GroupPoint")
     return out
 
@@ -116,7 +166,8 @@ def three_nn(xyz1, xyz2):
     m = xyz2.shape[1]
     dist = torch.empty((b, n, 3), dtype=torch.float32, device=xyz1.device)
     idx = torch.empty((b, n, 3), dtype=torch.int32, device=xyz1.device)
-    _lib.check(_lib.lib().prcnn_three_nn(b, n, m, _p(xyz1), _p(xyz2), _p(dist), _p(idx), _stream()),
+    _lib.check(_run("three_nn", {"tests": b * n * m, "bytes": b * (12 * n + 12 * m + 24 * n)},
+                    lambda: _lib.lib().prcnn_three_nn(b, n, m, _p(xyz1), _p(xyz2), _p(dist), _p(idx), _stream())),
                "ThreeNN")
     return dist, idx
 
@@ -131,8 +182,9 @@ def three_interpolate(points, idx, weight):
     b, m, c = points.shape
     n = idx.shape[1]
     out = torch.empty((b, n, c), dtype=torch.float32, device=points.device)
-    _lib.check(_lib.lib().prcnn_three_interpolate(b, m, c, n, _p(points), _p(idx), _p(weight),
-                                                  _p(out), _stream()), "ThreeInterpolate")
+    _lib.check(_run("three_interpolate", {"bytes": b * n * (24 + 16 * c)},
+                    lambda: _lib.lib().prcnn_three_interpolate(b, m, c, n, _p(points), _p(idx), _p(weight),
+                                                               _p(out), _stream())), "ThreeInterpolate")
     return out
 
 
@@ -164,8 +216,9 @@ def three_nn_interpolate(xyz1, xyz2, points2, out=None, return_nn=False):
     if return_nn:
         dist = torch.empty((b, n, 3), dtype=torch.float32, device=xyz1.device)
         idx = torch.empty((b, n, 3), dtype=torch.int32, device=xyz1.device)
-    _lib.check(_lib.lib().prcnn_three_nn_interpolate(b, n, m, c, _p(xyz1), _p(xyz2), _p(points2), _p(out),
-                                                     out.shape[2], _p(dist), _p(idx), _stream()),
+    _lib.check(_run("three_nn_interpolate", {"tests": b * n * m, "bytes": b * (12 * n + 12 * m) + b * n * 16 * c},
+                    lambda: _lib.lib().prcnn_three_nn_interpolate(b, n, m, c, _p(xyz1), _p(xyz2), _p(points2), _p(out),
+                                                                  out.shape[2], _p(dist), _p(idx), _stream())),
                "three_nn_interpolate")
     return (out, dist, idx) if return_nn else out
 
@@ -199,8 +252,10 @@ def mlp_layer(x, w, scale, shift, relu=True, pool=1, precision=PRECISION_FP32, o
         res = out
         ldo = out.shape[-1]
         optr = out.data_ptr() + 4 * out_col
-    _lib.check(L.prcnn_mlp_layer(rows, cin, cout, _p(x), cin, _p(w), _p(scale), _p(shift), int(relu),
-                                 int(pool), int(precision), optr, ldo, _stream()), "mlp_layer")
+    _lib.check(_run("mlp_layer", {"flops": 2 * rows * cin * cout,
+                                   "bytes": 4 * (rows * cin + cin * cout + (rows // pool) * cout)},
+                    lambda: L.prcnn_mlp_layer(rows, cin, cout, _p(x), cin, _p(w), _p(scale), _p(shift), int(relu),
+                                              int(pool), int(precision), optr, ldo, _stream())), "mlp_layer")
     return res
 
 
@@ -230,8 +285,11 @@ def sa_group_mlp_layer(xyz, feats, new_xyz, idx, w, scale, shift, xyz_first=Fals
         out = torch.empty((b, m, cout), dtype=torch.float32, device=xyz.device)
     else:
         out = torch.empty((b, m, ns, cout), dtype=torch.float32, device=xyz.device)
-    _lib.check(_lib.lib().prcnn_sa_group_mlp_layer(
+    rows = b * m * ns
+    _lib.check(_run("sa_group_mlp_layer", {"flops": 2 * rows * (c + 3) * cout,
+                                           "bytes": rows * (4 + 4 * (c + 3)) + 4 * (rows // pool) * cout},
+                    lambda: _lib.lib().prcnn_sa_group_mlp_layer(
         b, n, m, ns, c, _p(xyz), _p(feats), _p(new_xyz), _p(idx), int(bool(xyz_first)), cout, _p(w),
-        _p(scale), _p(shift), int(relu), int(pool), int(precision), _p(out), cout, _stream()),
+        _p(scale), _p(shift), int(relu), int(pool), int(precision), _p(out), cout, _stream())),
         "sa_group_mlp_layer")
     return out

@@ -59,9 +59,9 @@ def make_inputs(rank, device, batch):
     return pcs, prop
 
 
-def step(pcs, prop, store, precision):
+def step(pcs, prop, store, precision, geo=None):
     """SA+FP stack on the batch, per-scene rotated NMS of its proposals, detection records."""
-    feats, _ = stacks.rpn_sa_fp_stack(pcs, params=store, precision=precision)
+    feats, _ = stacks.rpn_sa_fp_stack(pcs, params=store, precision=precision, geometry_stream=geo)
     keep, nk = nms_rotate_batched(prop["bev"], prop["scores"], 0.8, pdist.MAX_DET)
     rec = pdist.pack_detections(prop["scene_ids"], prop["boxes3d"], prop["scores"], keep, nk)
     return feats, rec
@@ -127,9 +127,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32")
-    ap.add_argument("--streams", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=3)  # concurrent batches in flight
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--geo-stream", action="store_true",
+                    help="run each step's FPS chain on a companion stream (helps only single-batch latency)")
     ap.add_argument("--no-graph", action="store_true", help="issue every step eagerly instead of replaying HIP graphs")
     args = ap.parse_args()
 
@@ -142,18 +144,20 @@ def main():
     store = PU.ParamStore(seed=7, device=device)
     pcs, prop = make_inputs(rank, device, args.batch)
     streams = [torch.cuda.Stream(device=device) for _ in range(max(1, args.streams))]
+    # each step stream has a companion stream for its farthest-point-sampling chain
+    geos = [torch.cuda.Stream(device=device) if args.geo_stream else None for _ in streams]
 
     # One HIP graph of the whole step per stream (the C ABI allocates nothing and never
     # synchronises, so it captures as is); the all-gather stays outside the graph.
     graphs, outs = [], []
     if not args.no_graph:
-        for st in streams:
+        for st, geo in zip(streams, geos):
             with torch.cuda.stream(st):
-                step(pcs, prop, store, precision)                  # lazy init + allocator warm-up
+                step(pcs, prop, store, precision, geo)             # lazy init + allocator warm-up
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=st):
-                o = step(pcs, prop, store, precision)
+                o = step(pcs, prop, store, precision, geo)
             graphs.append(g); outs.append(o)
 
     def run_steps(k, timer=None):
@@ -166,7 +170,7 @@ def main():
                         graphs[j].replay()
                         rec = outs[j][1]
                     else:
-                        rec = step(pcs, prop, store, precision)[1]
+                        rec = step(pcs, prop, store, precision, None if timer is not None else geos[j])[1]
                     pdist.all_gather_detections(rec)
         finally:
             ops.set_timer(prev)
@@ -191,8 +195,11 @@ def main():
     # Instrumented pass (eager, HIP events around every launch, same streams and steps):
     # per-kernel durations for the roofline numbers.  Not part of `value`.
     timer = ops.KernelTimer()
-    run_steps(min(args.steps, 6), timer)
+    one = streams[:1]
+    streams, one = one, streams          # instrumented pass: ONE stream, so no kernel overlaps another
+    run_steps(min(args.steps, 4), timer)
     fence()
+    streams = one
 
     if rank == 0:
         scenes = args.batch * args.steps * world
@@ -240,8 +247,9 @@ def main():
                                    (args.batch, NPTS, NPROP, " + RCCL all-gather of detections" if world > 1 else ""),
                        "batch_per_gpu": args.batch, "points": NPTS, "streams": len(streams),
                        "hip_graph": bool(graphs), "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3),
-                       "kernel_timing": "HIP events around every launch in an eager instrumented pass "
-                                        "of the same steps after the timed region",
+                       "geometry_streams": bool(args.geo_stream),
+                       "kernel_timing": "HIP events around every launch in an eager, single-stream instrumented "
+                                        "pass of the same steps after the timed region",
                        "parallelism": "scene-sharded x%d" % world},
             "roofline": roof, "kernels": kernels, "fps": fps,
             "nms": {"ms_9000_to_100": round(nms_ms, 4), "kept": nms_keep, "pairs": 9000 * 8999 // 2,

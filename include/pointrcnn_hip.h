@@ -79,6 +79,17 @@ int prcnn_query_ball_point(int b, int n, int m, float radius, int nsample,
                            const float *xyz1, const float *xyz2, int *idx, int *pts_cnt,
                            prcnn_stream_t stream);
 
+/* Multi-scale form: the `nscales` (<= 4) ball queries of one MSG set-abstraction level
+ * (models/pointnet_util.py:174-177 calls query_ball_point once per radius on the same
+ * xyz1 / xyz2) in ONE pass over the points: each squared distance is evaluated once and
+ * tested against every radius.  host_* arrays live in HOST memory and are read before the
+ * call returns; host_idx[s] / host_pts_cnt[s] are device pointers (b,m,nsample[s]) / (b,m).
+ * Results are identical to nscales separate prcnn_query_ball_point calls. */
+int prcnn_query_ball_point_msg(int b, int n, int m, int nscales, const float *host_radii,
+                               const int *host_nsamples, const float *xyz1, const float *xyz2,
+                               int *const *host_idx, int *const *host_pts_cnt,
+                               prcnn_stream_t stream);
+
 /* groupPointLauncher(int b,int n,int c,int m,int nsample,const float* points,
  *                    const int* idx,float* out)   tf_grouping.cpp:142, tf_grouping_g.cu:40-57
  * out[b,j,k,:] = points[b,idx[b,j,k],:]  -> (b,m,nsample,c) */

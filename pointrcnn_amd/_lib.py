@@ -27,6 +27,7 @@ SIGNATURES = {
     "prcnn_fps_temp_bytes": (_sz, [_i, _i]),
     "prcnn_gather_point": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "prcnn_query_ball_point": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "prcnn_query_ball_point_msg": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "prcnn_group_point": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "prcnn_three_nn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "prcnn_three_interpolate": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

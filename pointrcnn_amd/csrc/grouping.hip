@@ -27,20 +27,31 @@ constexpr int BQ_CPW = 4;                         // centroids per wave
 constexpr int BQ_CPB = BQ_WAVES * BQ_CPW;         // centroids per workgroup
 constexpr int BQ_TILE = 2048;                     // candidate points per LDS tile
 
-__global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(
-    int n, int m, float thr2, int nsample, const float *__restrict__ xyz1,
-    const float *__restrict__ xyz2, int *__restrict__ idx, int *__restrict__ pts_cnt)
+struct BallScales {            // up to BQ_MAX_SCALES radii evaluated in one pass (MSG grouping)
+    float thr2[4];
+    int nsample[4];
+    int *idx[4];
+    int *pts_cnt[4];
+};
+constexpr int BQ_MAX_SCALES = 4;
+
+template <int NS>
+__global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(int n, int m, const BallScales sc,
+                                                                const float *__restrict__ xyz1,
+                                                                const float *__restrict__ xyz2)
 {
     __shared__ float sx[BQ_TILE], sy[BQ_TILE], sz[BQ_TILE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-uniform by construction; readfirstlane tells the compiler, so that the per-centroid
+    // counters, flags and centroid coordinates live in SGPRs and all control flow is scalar
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bi = blockIdx.y;
     const float *pts = xyz1 + (size_t)bi * n * 3;
     const float *cen = xyz2 + (size_t)bi * m * 3;
-    int *oidx = idx + (size_t)bi * m * nsample;
 
     const int j0 = (blockIdx.x * BQ_WAVES + wave) * BQ_CPW;
     float cx[BQ_CPW], cy[BQ_CPW], cz[BQ_CPW];
-    int cnt[BQ_CPW], first[BQ_CPW];
+    int cnt[BQ_CPW][NS], first[BQ_CPW][NS];
 #pragma unroll
     for (int c = 0; c < BQ_CPW; ++c) {
         const int j = j0 + c;
@@ -48,55 +59,64 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(
         cx[c] = ok ? cen[j * 3 + 0] : 0.f;
         cy[c] = ok ? cen[j * 3 + 1] : 0.f;
         cz[c] = ok ? cen[j * 3 + 2] : 0.f;
-        cnt[c] = ok ? 0 : nsample;                  // out-of-range centroid: already "full"
-        first[c] = 0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            cnt[c][s] = ok ? 0 : sc.nsample[s];          // out-of-range centroid: already "full"
+            first[c][s] = 0;
+        }
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
 
+    const float nanv = __builtin_nanf("");
     for (int base = 0; base < n; base += BQ_TILE) {
         const int tn = min(BQ_TILE, n - base);
+        const int tn64 = (tn + 63) & ~63;
         __syncthreads();
         for (int e = tid; e < tn * 3; e += BQ_THREADS) {
             const float v = pts[(size_t)base * 3 + e];
             const int p = e / 3, c = e - p * 3;
             (c == 0 ? sx : c == 1 ? sy : sz)[p] = v;
         }
+        // tail of the last 64-point chunk: NaN coordinates never pass  d2 < thr2
+        for (int p = tn + tid; p < tn64; p += BQ_THREADS) { sx[p] = nanv; sy[p] = nanv; sz[p] = nanv; }
         __syncthreads();
-        bool wave_done = true;
+        for (int p0 = 0; p0 < tn64; p0 += 64) {
+            bool any_active = false;                 // wave-uniform
+            const float x1 = sx[p0 + lane], y1 = sy[p0 + lane], z1 = sz[p0 + lane];
+            const int k = base + p0 + lane;
 #pragma unroll
-        for (int c = 0; c < BQ_CPW; ++c) wave_done = wave_done && cnt[c] >= nsample;
-        if (!wave_done) {
-            for (int p0 = 0; p0 < tn; p0 += 64) {
-                const int p = p0 + lane;
-                const bool valid = p < tn;
-                const float x1 = valid ? sx[p] : 0.f;
-                const float y1 = valid ? sy[p] : 0.f;
-                const float z1 = valid ? sz[p] : 0.f;
-                const int k = base + p;
-                bool all_done = true;
+            for (int c = 0; c < BQ_CPW; ++c) {
+                bool active = false;
 #pragma unroll
-                for (int c = 0; c < BQ_CPW; ++c) {
-                    if (cnt[c] < nsample) {          // wave-uniform
-                        const float dx = cx[c] - x1, dy = cy[c] - y1, dz = cz[c] - z1;
-                        const float d2 = dx * dx + dy * dy + dz * dz;
-                        const bool hit = valid && d2 < thr2;
-                        const unsigned long long mask = __ballot(hit);
-                        if (mask) {
-                            if (cnt[c] == 0) first[c] = base + p0 + __builtin_ctzll(mask);
-                            const int slot = cnt[c] + __builtin_popcountll(mask & lt);
-                            if (hit && slot < nsample) oidx[(size_t)(j0 + c) * nsample + slot] = k;
-                            cnt[c] += __builtin_popcountll(mask);
+                for (int s = 0; s < NS; ++s) active = active || cnt[c][s] < sc.nsample[s];
+                if (active) {
+                    const float dx = cx[c] - x1, dy = cy[c] - y1, dz = cz[c] - z1;
+                    const float d2 = dx * dx + dy * dy + dz * dz;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        if (cnt[c][s] < sc.nsample[s]) {
+                            const bool hit = d2 < sc.thr2[s];
+                            const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                            if (mask) {
+                                if (cnt[c][s] == 0) first[c][s] = base + p0 + __builtin_ctzll(mask);
+                                const int slot = cnt[c][s] + __builtin_popcountll(mask & lt);
+                                if (hit && slot < sc.nsample[s])
+                                    sc.idx[s][((size_t)bi * m + j0 + c) * sc.nsample[s] + slot] = k;
+                                cnt[c][s] += __builtin_popcountll(mask);
+                            }
                         }
-                        all_done = all_done && cnt[c] >= nsample;
                     }
+                    any_active = true;
                 }
-                if (all_done) break;
             }
+            if (!any_active) break;
         }
         // the whole workgroup leaves once every centroid of every wave is full
         bool done = true;
 #pragma unroll
-        for (int c = 0; c < BQ_CPW; ++c) done = done && cnt[c] >= nsample;
+        for (int c = 0; c < BQ_CPW; ++c)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) done = done && cnt[c][s] >= sc.nsample[s];
         if (__syncthreads_and(done)) break;
     }
     // pad rows that found fewer than nsample points with the first hit
@@ -105,10 +125,15 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(
     for (int c = 0; c < BQ_CPW; ++c) {
         const int j = j0 + c;
         if (j < m) {
-            const int cc = min(cnt[c], nsample);
-            if (cc > 0)
-                for (int l = cc + lane; l < nsample; l += 64) oidx[(size_t)j * nsample + l] = first[c];
-            if (pts_cnt && lane == 0) pts_cnt[(size_t)bi * m + j] = cc;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int ns = sc.nsample[s];
+                const int cc = min(cnt[c][s], ns);
+                int *row = sc.idx[s] + ((size_t)bi * m + j) * ns;
+                if (cc > 0)
+                    for (int l = cc + lane; l < ns; l += 64) row[l] = first[c][s];
+                if (sc.pts_cnt[s] && lane == 0) sc.pts_cnt[s][(size_t)bi * m + j] = cc;
+            }
         }
     }
 }
@@ -151,23 +176,49 @@ static float ball_threshold(float radius)
 
 }  // namespace prcnn
 
+extern "C" int prcnn_query_ball_point_msg(int b, int n, int m, int nscales, const float *host_radii,
+                                          const int *host_nsamples, const float *xyz1,
+                                          const float *xyz2, int *const *host_idx,
+                                          int *const *host_pts_cnt, prcnn_stream_t stream)
+{
+    using namespace prcnn;
+    if (nscales < 1 || nscales > BQ_MAX_SCALES) return PRCNN_UNSUPPORTED;
+    if (!host_radii || !host_nsamples || !host_idx) return PRCNN_BAD_SHAPE;
+    BallScales sc = {};
+    for (int s = 0; s < nscales; ++s) {
+        if (!(host_radii[s] > 0.0f)) return PRCNN_BAD_ARG;       // tf_grouping.cpp:71
+        if (host_nsamples[s] <= 0) return PRCNN_BAD_ARG;         // tf_grouping.cpp:74
+        sc.thr2[s] = ball_threshold(host_radii[s]);
+        sc.nsample[s] = host_nsamples[s];
+        sc.idx[s] = host_idx[s];
+        sc.pts_cnt[s] = host_pts_cnt ? host_pts_cnt[s] : nullptr;
+    }
+    if (b < 0 || n <= 0 || m < 0) return PRCNN_BAD_SHAPE;
+    if (b == 0 || m == 0) return PRCNN_OK;
+    if (!xyz1 || !xyz2) return PRCNN_BAD_SHAPE;
+    for (int s = 0; s < nscales; ++s)
+        if (!sc.idx[s]) return PRCNN_BAD_SHAPE;
+    if (b > 65535) return PRCNN_UNSUPPORTED;
+    dim3 grid((m + BQ_CPB - 1) / BQ_CPB, b);
+    hipStream_t st = to_stream(stream);
+    switch (nscales) {
+        case 1: hipLaunchKernelGGL(ball_query_kernel<1>, grid, dim3(BQ_THREADS), 0, st, n, m, sc, xyz1, xyz2); break;
+        case 2: hipLaunchKernelGGL(ball_query_kernel<2>, grid, dim3(BQ_THREADS), 0, st, n, m, sc, xyz1, xyz2); break;
+        case 3: hipLaunchKernelGGL(ball_query_kernel<3>, grid, dim3(BQ_THREADS), 0, st, n, m, sc, xyz1, xyz2); break;
+        default: hipLaunchKernelGGL(ball_query_kernel<4>, grid, dim3(BQ_THREADS), 0, st, n, m, sc, xyz1, xyz2); break;
+    }
+    PRCNN_LAUNCH_CHECK();
+    return PRCNN_OK;
+}
+
 extern "C" int prcnn_query_ball_point(int b, int n, int m, float radius, int nsample,
                                       const float *xyz1, const float *xyz2, int *idx,
                                       int *pts_cnt, prcnn_stream_t stream)
 {
-    using namespace prcnn;
-    if (!(radius > 0.0f)) return PRCNN_BAD_ARG;       // tf_grouping.cpp:71
-    if (nsample <= 0) return PRCNN_BAD_ARG;           // tf_grouping.cpp:74
-    if (b < 0 || n <= 0 || m < 0) return PRCNN_BAD_SHAPE;
-    if (b == 0 || m == 0) return PRCNN_OK;
-    if (!xyz1 || !xyz2 || !idx) return PRCNN_BAD_SHAPE;
-    if (b > 65535) return PRCNN_UNSUPPORTED;
-    const float thr2 = ball_threshold(radius);
-    dim3 grid((m + BQ_CPB - 1) / BQ_CPB, b);
-    hipLaunchKernelGGL(ball_query_kernel, grid, dim3(BQ_THREADS), 0, to_stream(stream), n, m, thr2,
-                       nsample, xyz1, xyz2, idx, pts_cnt);
-    PRCNN_LAUNCH_CHECK();
-    return PRCNN_OK;
+    if (!idx && b > 0 && m > 0 && radius > 0.0f && nsample > 0 && n > 0) return PRCNN_BAD_SHAPE;
+    int *idxs[1] = {idx};
+    int *cnts[1] = {pts_cnt};
+    return prcnn_query_ball_point_msg(b, n, m, 1, &radius, &nsample, xyz1, xyz2, idxs, cnts, stream);
 }
 
 extern "C" int prcnn_group_point(int b, int n, int c, int m, int nsample, const float *points,

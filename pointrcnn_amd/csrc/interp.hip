@@ -18,7 +18,7 @@
 
 namespace prcnn {
 
-constexpr int NN_THREADS = 128;
+constexpr int NN_THREADS = 256;
 constexpr int NN_TILE = 2048;
 
 struct Top3 {
@@ -26,25 +26,46 @@ struct Top3 {
     int i1, i2, i3;
 };
 
+__device__ __forceinline__ void top3_insert(Top3 &t, float d, int kk)
+{
+    if (d < t.d3) {                                   // tf_interpolate.cpp:74-89
+        if (d < t.d1) {
+            t.d3 = t.d2; t.i3 = t.i2;
+            t.d2 = t.d1; t.i2 = t.i1;
+            t.d1 = d; t.i1 = kk;
+        } else if (d < t.d2) {
+            t.d3 = t.d2; t.i3 = t.i2;
+            t.d2 = d; t.i2 = kk;
+        } else {
+            t.d3 = d; t.i3 = kk;
+        }
+    }
+}
+
+__device__ __forceinline__ float sqdist(const float4 p, float x1, float y1, float z1)
+{
+    const float dx = p.x - x1, dy = p.y - y1, dz = p.z - z1;
+    return dx * dx + dy * dy + dz * dz;               // tf_interpolate.cpp:73, unfused
+}
+
+// The tile is padded to a multiple of 4 with NaN points (never smaller than anything).
+// Four candidates per step; the insertion chain only runs when one of them can enter the
+// top 3, and then visits them in index order, so ties resolve exactly as in the reference.
 __device__ __forceinline__ void top3_scan(Top3 &t, float x1, float y1, float z1,
                                           const float4 *__restrict__ tile, int tn, int base)
 {
-    for (int k = 0; k < tn; ++k) {
-        const float4 p = tile[k];
-        const float dx = p.x - x1, dy = p.y - y1, dz = p.z - z1;
-        const float d = dx * dx + dy * dy + dz * dz;
-        if (d < t.d3) {
-            const int kk = base + k;
-            if (d < t.d1) {
-                t.d3 = t.d2; t.i3 = t.i2;
-                t.d2 = t.d1; t.i2 = t.i1;
-                t.d1 = d; t.i1 = kk;
-            } else if (d < t.d2) {
-                t.d3 = t.d2; t.i3 = t.i2;
-                t.d2 = d; t.i2 = kk;
-            } else {
-                t.d3 = d; t.i3 = kk;
-            }
+    const int tn4 = (tn + 3) & ~3;
+    for (int k = 0; k < tn4; k += 4) {
+        const float d0 = sqdist(tile[k], x1, y1, z1);
+        const float d1 = sqdist(tile[k + 1], x1, y1, z1);
+        const float d2 = sqdist(tile[k + 2], x1, y1, z1);
+        const float d3 = sqdist(tile[k + 3], x1, y1, z1);
+        const float mn = fminf(fminf(d0, d1), fminf(d2, d3));
+        if (mn < t.d3) {
+            top3_insert(t, d0, base + k);
+            top3_insert(t, d1, base + k + 1);
+            top3_insert(t, d2, base + k + 2);
+            top3_insert(t, d3, base + k + 3);
         }
     }
 }
@@ -52,9 +73,15 @@ __device__ __forceinline__ void top3_scan(Top3 &t, float x1, float y1, float z1,
 __device__ __forceinline__ void stage_tile(float4 *tile, const float *__restrict__ known, int base,
                                            int tn, int tid, int nthreads)
 {
-    for (int k = tid; k < tn; k += nthreads) {
-        const float *p = known + (size_t)(base + k) * 3;
-        tile[k] = make_float4(p[0], p[1], p[2], 0.f);
+    const int tn4 = (tn + 3) & ~3;
+    const float nan = __builtin_nanf("");
+    for (int k = tid; k < tn4; k += nthreads) {
+        if (k < tn) {
+            const float *p = known + (size_t)(base + k) * 3;
+            tile[k] = make_float4(p[0], p[1], p[2], 0.f);
+        } else {
+            tile[k] = make_float4(nan, nan, nan, 0.f);
+        }
     }
 }
 

@@ -138,6 +138,32 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     return idx, cnt
 
 
+def query_ball_point_msg(radius_list, nsample_list, xyz1, xyz2):
+    """All ball queries of one MSG level in a single pass (same results as one
+    query_ball_point call per radius).  Returns [(idx, pts_cnt), ...]."""
+    import ctypes
+    xyz1 = _dev(xyz1, torch.float32, "QueryBallPoint xyz1", 3, 3)
+    xyz2 = _dev(xyz2, torch.float32, "QueryBallPoint xyz2", 3, 3)
+    if xyz1.shape[0] != xyz2.shape[0]:
+        raise ValueError("QueryBallPoint expects equal batch sizes")
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    k = len(radius_list)
+    if k > 4:
+        return [query_ball_point(r, ns, xyz1, xyz2) for r, ns in zip(radius_list, nsample_list)]
+    res = [(torch.zeros((b, m, max(int(ns), 0)), dtype=torch.int32, device=xyz1.device),
+            torch.empty((b, m), dtype=torch.int32, device=xyz1.device)) for ns in nsample_list]
+    radii = (ctypes.c_float * k)(*[float(r) for r in radius_list])
+    nss = (ctypes.c_int * k)(*[int(ns) for ns in nsample_list])
+    idxs = (ctypes.c_void_p * k)(*[t[0].data_ptr() for t in res])
+    cnts = (ctypes.c_void_p * k)(*[t[1].data_ptr() for t in res])
+    _lib.check(_run("query_ball_point", {"tests": b * m * n,
+                                         "bytes": b * (12 * n + 12 * m + sum(4 * m * int(ns) + 4 * m for ns in nsample_list))},
+                    lambda: _lib.lib().prcnn_query_ball_point_msg(b, n, m, k, radii, nss, _p(xyz1), _p(xyz2), idxs, cnts,
+                                                                  _stream())), "QueryBallPoint")
+    return res
+
+
 def group_point(points, idx):
     """tf_grouping.py:34-42.  points (b,n,c), idx (b,m,nsample) -> (b,m,nsample,c)."""
     points = _dev(points, torch.float32, "GroupPoint points", 3)       # tf_grouping.cpp:147

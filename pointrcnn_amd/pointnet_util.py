@@ -173,7 +173,7 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
 
 def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_list, is_training,
                            bn_decay, scope, bn=True, use_xyz=True, use_nchw=False, params=None,
-                           precision=None):
+                           precision=None, new_xyz=None):
     """models/pointnet_util.py:155-195 -> new_xyz (b,npoint,3), new_points (b,npoint,sum mlp[k][-1]).
     Channel order inside each scale is [features, xyz_local] (:183)."""
     _check_inference(is_training)
@@ -182,14 +182,17 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
     store = params if params is not None else get_params()
     precision = PRECISION if precision is None else precision
     b = xyz.shape[0]
-    new_xyz = ops.gather_point(xyz, ops.farthest_point_sample(npoint, xyz))
+    if new_xyz is None:    # a caller may have sampled the centroids already (on another stream)
+        new_xyz = ops.gather_point(xyz, ops.farthest_point_sample(npoint, xyz))
     ctot = sum(m[-1] for m in mlp_list)
     out = torch.empty((b, npoint, ctot), dtype=torch.float32, device=xyz.device)
     col = 0
     c_feat = 0 if points is None else points.shape[2]
+    # FUSED: one pass over the points answers the ball queries of every scale
+    balls = ops.query_ball_point_msg(radius_list, nsample_list, xyz, new_xyz) if FUSED else None
     for i in range(len(radius_list)):
         radius, nsample, mlp = radius_list[i], nsample_list[i], mlp_list[i]
-        idx, pts_cnt = ops.query_ball_point(radius, nsample, xyz, new_xyz)
+        idx, pts_cnt = balls[i] if balls is not None else ops.query_ball_point(radius, nsample, xyz, new_xyz)
         fusable = FUSED and (use_xyz or points is None) and nsample % 16 == 0 and 128 % nsample == 0
         if fusable:
             W, s, t = store.layer('%s/conv%d_0' % (scope, i), c_feat + 3, mlp[0], bn)

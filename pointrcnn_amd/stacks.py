@@ -23,15 +23,47 @@ RPN_SA = [
 RPN_FP = [[512, 512], [512, 512], [256, 256], [128, 128]]
 
 
-def rpn_sa_fp_stack(point_cloud, params=None, precision=None, is_training=False, bn_decay=None):
-    """point_cloud (B,N,4) -> per-point features (B,N,128); also returns the level xyz/feature lists."""
+def sample_centroid_chain(l0_xyz, npoints, stream=None):
+    """FPS + gather for every level: l0 -> l1 -> ... depends on coordinates only, so the
+    whole (strictly serial, latency-bound) chain can run on a side stream while the main
+    stream does the feature work of the levels already sampled.  Returns the list of
+    new_xyz tensors and one event per level recorded on `stream`."""
+    from . import ops
+    xs, evs = [], []
+    cur = torch.cuda.current_stream()
+    side = stream if stream is not None else cur
+    if stream is not None:
+        side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        x = l0_xyz
+        for m in npoints:
+            x = ops.gather_point(x, ops.farthest_point_sample(m, x))
+            xs.append(x)
+            if stream is not None:
+                ev = torch.cuda.Event()
+                ev.record(side)
+                evs.append(ev)
+                x.record_stream(cur)
+    return xs, evs
+
+
+def rpn_sa_fp_stack(point_cloud, params=None, precision=None, is_training=False, bn_decay=None,
+                    geometry_stream=None):
+    """point_cloud (B,N,4) -> per-point features (B,N,128); also returns the level xyz/feature lists.
+    With `geometry_stream` the FPS chain of all four levels runs on that stream, overlapped
+    with the grouping / MLP work of the main stream (same results)."""
     l0_xyz = point_cloud[:, :, 0:3].contiguous()
     l0_points = point_cloud[:, :, 3:].contiguous() if point_cloud.shape[2] > 3 else None
     xyzs, feats = [l0_xyz], [l0_points]
+    pre, evs = (None, None)
+    if geometry_stream is not None:
+        pre, evs = sample_centroid_chain(l0_xyz, [lv[0] for lv in RPN_SA], geometry_stream)
     for li, (npoint, radii, nsamples, mlps) in enumerate(RPN_SA):
+        if pre is not None:
+            torch.cuda.current_stream().wait_event(evs[li])
         x, f = pointnet_sa_module_msg(xyzs[-1], feats[-1], npoint, radii, nsamples, mlps, is_training,
                                       bn_decay, scope='layer%d' % (li + 1), bn=True, params=params,
-                                      precision=precision)
+                                      precision=precision, new_xyz=None if pre is None else pre[li])
         xyzs.append(x)
         feats.append(f)
     l3 = pointnet_fp_module(xyzs[3], xyzs[4], feats[3], feats[4], RPN_FP[0], is_training, bn_decay,

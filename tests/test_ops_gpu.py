@@ -205,3 +205,14 @@ def test_fused_three_nn_interpolate(cuda, n, m, c, extra):
     assert np.allclose(got[:, :, :c], ref, rtol=1e-5, atol=1e-6)
     assert np.array_equal(got[:, :, :c], ref)                  # and in fact bit-exact
     assert (got[:, :, c:] == -7.0).all()                       # the rest of the concat buffer is untouched
+
+
+def test_query_ball_msg_equals_per_radius_calls(cuda):
+    pts = S.kitti_batch(5, 2, 4096)[:, :, :3]
+    cen = O.gather_point(pts, O.farthest_point_sample(300, pts))
+    for radii, nss in (([0.1, 0.5], [16, 32]), ([0.2, 0.4, 0.8], [32, 64, 128]), ([1.0], [8]),
+                       ([0.3, 0.3, 2.0, 0.05], [16, 4, 64, 8])):
+        res = ops.query_ball_point_msg(radii, nss, dev(pts, cuda), dev(cen, cuda))
+        for (idx, cnt), r, ns in zip(res, radii, nss):
+            oi, oc = O.query_ball_point(r, ns, pts, cen)
+            assert np.array_equal(npy(idx), oi) and np.array_equal(npy(cnt), oc)

@@ -14,6 +14,8 @@ LIB = os.path.join(HERE, "libpointrcnn_hip.so")
 SOURCES = ["c_api.hip", "fps.hip", "grouping.hip", "interp.hip", "nms_rotate.hip", "mlp.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
          "-Wall", "-Wno-unused-function"]
+# per-file extra flags (measured choices)
+EXTRA = {}
 
 
 def build(force=False, verbose=False):
@@ -29,7 +31,7 @@ def build(force=False, verbose=False):
         objs.append(obj)
         newest = max(os.path.getmtime(p) for p in [src] + deps)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + EXTRA.get(s, []) + os.environ.get("PRCNN_EXTRA_FLAGS", "").split() + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((s, subprocess.Popen(cmd)))

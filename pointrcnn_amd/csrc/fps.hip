@@ -8,8 +8,10 @@
 //     min-distance array in VGPRs (n <= 16384) or in LDS (n <= 32768): no global or
 //     LDS traffic in the distance loop;
 //   * per iteration ONE barrier: wave argmax by DPP max + ballot (first lane = lowest
-//     thread slot), one LDS record per wave (double-buffered by iteration parity),
-//     every wave re-reduces the <=16 records redundantly.
+//     thread slot), then one 64-bit LDS atomic max per wave on (value, ~tie-break key)
+//     into a rotating slot that every lane reads back after the barrier;
+//   * distances of two points per packed fp32 instruction (v_pk_add/mul_f32: measured
+//     faster than the scalar form on gfx950, and bit-identical per component).
 // Bit-exactness contract: fp32 d=(dx*dx+dy*dy)+dz*dz without FMA
 // contraction (file is built with -ffp-contract=off), temp=min(d,temp), winner =
 // (max value, smallest k mod 512, smallest k).  Lane t of the workgroup owns reference
@@ -19,7 +21,21 @@
 // compare run on the int bit patterns (order-preserving, no NaN canonicalisation code).
 #include "common.h"
 
+#ifndef PRCNN_FPS_PROBE
+#define PRCNN_FPS_PROBE 0      // diagnostic builds only: 1 = no coordinate load, 2 = no cross-wave step, 4 = no wave reduce
+#endif
+
 namespace prcnn {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// value (non-negative float bits or the -1.0f sentinel) and tie-break key packed so that
+// an unsigned 64-bit max picks (largest value, then smallest key)
+__device__ __forceinline__ unsigned long long fps_pack(int vbits, unsigned key)
+{
+    const unsigned hi = vbits < 0 ? 0u : (unsigned)vbits + 1u;
+    return ((unsigned long long)hi << 32) | (unsigned long long)(~key);
+}
 
 template <int PPT, int H, bool TD_LDS>
 __global__ __launch_bounds__(512 * H) void fps_kernel(int n, int m,
@@ -27,73 +43,89 @@ __global__ __launch_bounds__(512 * H) void fps_kernel(int n, int m,
                                                        int *__restrict__ idxs)
 {
     constexpr int T = 512 * H;
-    constexpr int NW = T / 64;
+    constexpr int P2 = (PPT + 1) / 2;      // points are processed in pairs (packed fp32 math)
     extern __shared__ __attribute__((aligned(16))) int smem[];
-    int *rec = smem;                       // [2][NW][2] = (value bits, k)
-    int *tdl = smem + 2 * NW * 2;          // TD_LDS: [PPT][T] running min distances
+    // three rotating 64-bit slots for the cross-wave argmax (ds_max_u64), see below
+    unsigned long long *slot = reinterpret_cast<unsigned long long *>(smem);
+    int *tdl = smem + 8;                   // TD_LDS: [2*P2][T] running min distances
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
     const int s = tid & 511;
     const int h = tid >> 9;
     const float *data = dataset + (size_t)blockIdx.x * n * 3;
     int *out = idxs + (size_t)blockIdx.x * m;
 
-    float px[PPT], py[PPT], pz[PPT];
-    int td[TD_LDS ? 1 : PPT];
+    f32x2 px[P2], py[P2], pz[P2];
+    int td[TD_LDS ? 1 : 2 * P2];
 #pragma unroll
-    for (int q = 0; q < PPT; ++q) {
+    for (int q = 0; q < 2 * P2; ++q) {
         const int k = s + 512 * (h * PPT + q);
-        const bool ok = k < n;
-        px[q] = ok ? data[k * 3 + 0] : 0.f;
-        py[q] = ok ? data[k * 3 + 1] : 0.f;
-        pz[q] = ok ? data[k * 3 + 2] : 0.f;
+        const bool ok = q < PPT && k < n;
+        px[q >> 1][q & 1] = ok ? data[k * 3 + 0] : 0.f;
+        py[q >> 1][q & 1] = ok ? data[k * 3 + 1] : 0.f;
+        pz[q >> 1][q & 1] = ok ? data[k * 3 + 2] : 0.f;
         const int init = ok ? f2i(1e38f) : f2i(-1.0f);   // -1: never beats best=-1
         if (TD_LDS) tdl[q * T + tid] = init; else td[q] = init;
     }
-    int old = 0;
+    if (tid < 3) slot[tid] = 0ull;
     if (tid == 0) out[0] = 0;
+    int old = 0;
+    __syncthreads();
 
     for (int j = 1; j < m; ++j) {
         const int so = __builtin_amdgcn_readfirstlane(old);
+#if (PRCNN_FPS_PROBE & 1)
+        const float x1 = so * 0.001f, y1 = so * 0.002f, z1 = so * 0.003f;
+#else
         const float x1 = data[so * 3 + 0];
         const float y1 = data[so * 3 + 1];
         const float z1 = data[so * 3 + 2];
+#endif
         int best = f2i(-1.0f);
         int bq = 0;
 #pragma unroll
-        for (int q = 0; q < PPT; ++q) {
-            const float dx = px[q] - x1, dy = py[q] - y1, dz = pz[q] - z1;
-            const float d = dx * dx + dy * dy + dz * dz;
-            const int t0 = TD_LDS ? tdl[q * T + tid] : td[q];
-            const int d2 = min(f2i(d), t0);
-            if (TD_LDS) { if (d2 != t0) tdl[q * T + tid] = d2; } else td[q] = d2;
-            bq = d2 > best ? q : bq;
-            best = max(best, d2);
+        for (int p = 0; p < P2; ++p) {
+            // two points per packed instruction; each component is an IEEE fp32 op, so the
+            // result equals the scalar expression (x2-x1)^2+(y2-y1)^2+(z2-z1)^2 bit for bit
+            const f32x2 dx = px[p] - x1, dy = py[p] - y1, dz = pz[p] - z1;
+            const f32x2 d = dx * dx + dy * dy + dz * dz;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = 2 * p + u;
+                const int t0 = TD_LDS ? tdl[q * T + tid] : td[q];
+                const int d2 = min(f2i(d[u]), t0);
+                if (TD_LDS) { if (d2 != t0) tdl[q * T + tid] = d2; } else td[q] = d2;
+                bq = d2 > best ? q : bq;
+                best = max(best, d2);
+            }
         }
         // reference: a slot with no strictly-better point reports besti = 0
         const int bk = best > f2i(-1.0f) ? s + 512 * (h * PPT + bq) : 0;
         // wave argmax: lanes are in slot order, so the first lane holding the max wins
+#if (PRCNN_FPS_PROBE & 4)
+        const int wmax = __builtin_amdgcn_readfirstlane(best);
+        const int wk = __builtin_amdgcn_readfirstlane(bk);
+#else
         const int wmax = wave_max_i32(best);
         const unsigned long long eq = __ballot(best == wmax);
         const int first = __builtin_ctzll(eq);
         const int wk = __builtin_amdgcn_readlane(bk, first);
-        const int par = j & 1;
-        if (lane == 0) {
-            rec[(par * NW + wave) * 2 + 0] = wmax;
-            rec[(par * NW + wave) * 2 + 1] = wk;
-        }
+#endif
+        // cross-wave argmax: one LDS atomic max per wave on (value, ~(k mod 512, k / 512)).
+        // Slot j%3 is used by iteration j; slot (j+2)%3 (last read in iteration j-1, next
+        // written in iteration j+2) is cleared after this iteration's barrier.
+#if (PRCNN_FPS_PROBE & 2)
+        old = (wk + (wmax & 1)) % n;
+#else
+        const int cur = j % 3;
+        if ((tid & 63) == 0)
+            atomicMax(&slot[cur], fps_pack(wmax, (unsigned)(((wk & 511) << 8) | (wk >> 9))));
         __syncthreads();
-        // every wave reduces the NW records: max value, then min (k mod 512, k / 512)
-        const int e = lane < NW ? lane : 0;
-        const int ev = rec[(par * NW + e) * 2 + 0];
-        const int ek = rec[(par * NW + e) * 2 + 1];
-        const int mv = row16_allmax_i32(ev);
-        const unsigned key = ev == mv ? (unsigned)(((ek & 511) << 8) | (ek >> 9)) : 0x7fffffffu;
-        const unsigned mk = row16_allmin_u32(key);
-        const int win = (int)((mk >> 8) + ((mk & 255u) << 9));
-        old = __builtin_amdgcn_readfirstlane(win);
+        const unsigned long long win = slot[cur];
+        if (tid == 0) slot[(j + 2) % 3] = 0ull;
+        const unsigned k2 = ~(unsigned)win;
+        old = (int)((k2 >> 8) + ((k2 & 255u) << 9));
+#endif
         if (tid == 0) out[j] = old;
     }
 }
@@ -174,7 +206,7 @@ template <int PPT, int H, bool TD_LDS>
 static int launch_fps(int b, int n, int m, const float *inp, int *out, hipStream_t st)
 {
     constexpr int T = 512 * H;
-    size_t lds = sizeof(int) * (2 * (T / 64) * 2 + (TD_LDS ? PPT * T : 0));
+    size_t lds = sizeof(int) * (8 + (TD_LDS ? 2 * ((PPT + 1) / 2) * T : 0));
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void *)fps_kernel<PPT, H, TD_LDS>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

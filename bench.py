@@ -220,15 +220,37 @@ def main():
             if "tests" in d:
                 e["gtests_per_s"] = round(d["tests"] / (d["ms"] * 1e-3) / 1e9, 2)
             kernels[name] = e
-        # dominant roofline-bound kernel family = the one with the most time among hbm/mfma ones
-        cand = [(v["ms_total"], k) for k, v in kernels.items() if "bound" in v]
-        dom = max(cand)[1] if cand else None
+        # dominant roofline-bound kernel = the single (kernel, shape) with the most time in the
+        # step among the HBM- / MFMA-bound ones
+        best = None
+        for (name, _), d in timer.summary(by_shape=True).items():
+            if "flops" in d:
+                peak = roofline.FP32_MFMA_PEAK_TFLOPS if precision == 0 else roofline.BF16_MFMA_PEAK_TFLOPS
+                cand = dict(kernel=name, shape=d.get("shape"), bound="mfma", unit="TFLOP/s", peak=peak,
+                            achieved=d["flops"] / (d["ms"] * 1e-3) / 1e12, algorithmic=d["flops"] // d["launches"])
+            elif name in ("group_point", "three_interpolate"):
+                cand = dict(kernel=name, shape=None, bound="hbm", unit="GB/s", peak=roofline.HBM_PEAK_GBS,
+                            achieved=d["bytes"] / (d["ms"] * 1e-3) / 1e9, algorithmic=d["bytes"] // d["launches"])
+            else:
+                continue
+            cand.update(ms=d["ms"], launches=d["launches"], avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2))
+            if best is None or cand["ms"] > best["ms"]:
+                best = cand
         roof = None
-        if dom:
-            v = kernels[dom]
-            roof = {"kernel": dom, "bound": v["bound"], "achieved": v["achieved"], "peak": v["peak"],
-                    "unit": v["unit"], "frac": v["frac"], "traffic": None,
-                    "avg_launch_us": v["avg_us"], "launches": v["launches"]}
+        if best:
+            traffic, tsrc = None, None
+            # HBM bytes per launch from the committed PMC passes (profiles/, same kernel and shape)
+            pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_hot_kernels.json")
+            if best["shape"] == "rows262144 K260 N128 pool1" and os.path.exists(pmc_path):
+                pm = json.load(open(pmc_path)).get("mlp_kernel<2, 2, 2, 2, false, false>")
+                if pm:
+                    traffic = pm["hbm_bytes_corrected"]
+                    tsrc = "profiles/r01_pmc_hot_kernels.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, read side x2)"
+            roof = {"kernel": best["kernel"], "shape": best["shape"], "bound": best["bound"],
+                    "achieved": round(best["achieved"], 3), "peak": best["peak"], "unit": best["unit"],
+                    "frac": round(best["achieved"] / best["peak"], 4), "traffic": traffic,
+                    "traffic_source": tsrc, "algorithmic_per_launch": best["algorithmic"],
+                    "avg_launch_us": best["avg_launch_us"], "launches": best["launches"]}
         fps = None
         if "fps" in ksum:
             d = ksum["fps"]

@@ -34,15 +34,20 @@ class KernelTimer:
         self.records.append((name, work, s, e))
         return rc
 
-    def summary(self):
+    def summary(self, by_shape=False):
+        """Per kernel family (or, with by_shape, per (family, identical work) = per shape)."""
         torch.cuda.synchronize()
         out = {}
         for name, work, s, e in self.records:
-            d = out.setdefault(name, {"launches": 0, "ms": 0.0})
+            key = (name, tuple(sorted(work.items()))) if by_shape else name
+            d = out.setdefault(key, {"launches": 0, "ms": 0.0})
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
             for k, v in work.items():
-                d[k] = d.get(k, 0) + v
+                if isinstance(v, str):
+                    d[k] = v
+                else:
+                    d[k] = d.get(k, 0) + v
         return out
 
 
@@ -278,7 +283,7 @@ def mlp_layer(x, w, scale, shift, relu=True, pool=1, precision=PRECISION_FP32, o
         res = out
         ldo = out.shape[-1]
         optr = out.data_ptr() + 4 * out_col
-    _lib.check(_run("mlp_layer", {"flops": 2 * rows * cin * cout,
+    _lib.check(_run("mlp_layer", {"shape": "rows%d K%d N%d pool%d" % (rows, cin, cout, pool), "flops": 2 * rows * cin * cout,
                                    "bytes": 4 * (rows * cin + cin * cout + (rows // pool) * cout)},
                     lambda: L.prcnn_mlp_layer(rows, cin, cout, _p(x), cin, _p(w), _p(scale), _p(shift), int(relu),
                                               int(pool), int(precision), optr, ldo, _stream())), "mlp_layer")
@@ -312,7 +317,8 @@ def sa_group_mlp_layer(xyz, feats, new_xyz, idx, w, scale, shift, xyz_first=Fals
     else:
         out = torch.empty((b, m, ns, cout), dtype=torch.float32, device=xyz.device)
     rows = b * m * ns
-    _lib.check(_run("sa_group_mlp_layer", {"flops": 2 * rows * (c + 3) * cout,
+    _lib.check(_run("sa_group_mlp_layer", {"shape": "rows%d K%d N%d pool%d" % (rows, c + 3, cout, pool),
+                                           "flops": 2 * rows * (c + 3) * cout,
                                            "bytes": rows * (4 + 4 * (c + 3)) + 4 * (rows // pool) * cout},
                     lambda: _lib.lib().prcnn_sa_group_mlp_layer(
         b, n, m, ns, c, _p(xyz), _p(feats), _p(new_xyz), _p(idx), int(bool(xyz_first)), cout, _p(w),

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""One launch of each hot kernel at its largest RPN-stack shape (batch 16), for rocprofv3
+counter passes (run each --pmc pass separately, see profiles/README.md):
+  rocprofv3 --kernel-trace --stats ...            durations
+  rocprofv3 --pmc FETCH_SIZE ...                  HBM read  (KB; x2 for wide coalesced reads on gfx950)
+  rocprofv3 --pmc WRITE_SIZE ...                  HBM write (KB)
+Each op is launched REPS times back to back; tools/pmc_summary.py averages per kernel name.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from pointrcnn_amd import ops, synthetic as S
+
+REPS = 3
+
+
+def main():
+    dev = torch.device("cuda:0")
+    b = 16
+    g = torch.Generator(device="cpu"); g.manual_seed(0)
+    pc = torch.as_tensor(S.kitti_batch(0, b)).to(dev)
+    xyz = pc[:, :, :3].contiguous()
+    feats = pc[:, :, 3:].contiguous()
+    new1 = ops.gather_point(xyz, ops.farthest_point_sample(4096, xyz))
+    new2 = ops.gather_point(new1, ops.farthest_point_sample(1024, new1))
+    f1 = torch.randn(b, 4096, 96, generator=g).to(dev)
+    f256 = torch.randn(b, 4096, 256, generator=g).to(dev)
+    (idx2, _), = ops.query_ball_point_msg([1.0], [32], new1, new2)
+    d, i3 = ops.three_nn(xyz, new1)
+    w = ops.fp_weights(d)
+    x260 = torch.randn(b * 16384, 260, generator=g).to(dev)
+    W260 = torch.randn(260, 128, generator=g).mul_(0.05).to(dev)
+    W99 = torch.randn(99, 64, generator=g).mul_(0.1).to(dev)
+    one = lambda c: (torch.ones(c, device=dev), torch.zeros(c, device=dev))
+    torch.cuda.synchronize()
+    work = {
+        "group_point_kernel<4>": b * 1024 * 32 * (4 + 8 * 96),
+        "three_interpolate_kernel<4>": b * 16384 * (24 + 16 * 256),
+        "three_nn_interpolate_kernel<4>": b * (12 * 16384 + 12 * 4096) + b * 16384 * 16 * 256,
+        "mlp_kernel<2, 2, 2, 2, false, false>": 4 * (b * 16384 * 260 + 260 * 128 + b * 16384 * 128),
+        "mlp_kernel<4, 1, 1, 2, true, false>": b * 1024 * 32 * (4 + 4 * 99) + 4 * b * 1024 * 32 * 64,
+    }
+    for _ in range(REPS):
+        ops.group_point(f1, idx2)
+        ops.three_interpolate(f256, i3, w)
+        ops.three_nn_interpolate(xyz, new1, f256)
+        ops.mlp_layer(x260, W260, *one(128))
+        ops.sa_group_mlp_layer(new1, f1, new2, idx2, W99, *one(64))
+        ops.query_ball_point_msg([0.1, 0.5], [16, 32], xyz, new1)
+        ops.farthest_point_sample(4096, xyz)
+    torch.cuda.synchronize()
+    import json
+    print(json.dumps({"algorithmic_bytes_per_launch": work}))
+
+
+if __name__ == "__main__":
+    main()

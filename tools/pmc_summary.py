@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 CSV output directories of tools/pmc_probe.py into one JSON:
+per kernel name: launches, average duration (kernel trace), FETCH_SIZE / WRITE_SIZE per launch.
+  python tools/pmc_summary.py <trace_dir> <fetch_dir> <write_dir> > profiles/xxx.json
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def rows(d, pat):
+    out = []
+    for f in glob.glob(os.path.join(d, "**", pat), recursive=True):
+        with open(f) as fh:
+            out += list(csv.DictReader(fh))
+    return out
+
+
+def short(name):
+    name = name.replace("void ", "").replace("prcnn::", "")
+    return name.split("(")[0]
+
+
+def main():
+    trace, fetch, write = sys.argv[1:4]
+    res = {}
+    for r in rows(trace, "*kernel_trace.csv"):
+        k = short(r["Kernel_Name"])
+        if "at::" in k or "rocclr" in k:
+            continue
+        d = res.setdefault(k, {"launches": 0, "ns": 0})
+        d["launches"] += 1
+        d["ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    for tag, dd in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
+        acc = {}
+        for r in rows(dd, "*counter_collection.csv"):
+            if r["Counter_Name"] != tag:
+                continue
+            k = short(r["Kernel_Name"])
+            a = acc.setdefault(k, [0, 0.0])
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+        for k, (n, v) in acc.items():
+            if k in res:
+                res[k][tag + "_KB_per_launch"] = v / n
+    for k, d in res.items():
+        d["avg_us"] = d.pop("ns") / d["launches"] / 1e3
+        f = d.get("FETCH_SIZE_KB_per_launch")
+        w = d.get("WRITE_SIZE_KB_per_launch")
+        if f is not None and w is not None:
+            # gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads
+            # (MI355X_MICROARCH.md, HBM): report both the raw and the x2-corrected read side
+            d["hbm_bytes_raw"] = (f + w) * 1024
+            d["hbm_bytes_corrected"] = (2 * f + w) * 1024
+    print(json.dumps(res, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()

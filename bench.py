@@ -81,6 +81,19 @@ def time_nms(device, n=9000, iters=20):
     return e0.elapsed_time(e1) / iters, int(nk.item())
 
 
+def time_fps_dense(device, n=131072, m=16384):
+    """BASELINE config 5, second half: FPS on a 131072-point dense scene."""
+    pts = torch.as_tensor(S.dense_scene(5000, n)[None, :, :3].copy()).to(device)
+    ops.farthest_point_sample(64, pts)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.farthest_point_sample(m, pts)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    return {"points": n, "npoint": m, "ms": round(ms, 3), "us_per_iteration": round(1e3 * ms / (m - 1), 4)}
+
+
 def cpu_baseline(store, seconds_cap=40.0):
     """The CPU oracle (reference CPU path: C++ CPU ops restated + transcribed FPS kernel)
     on ONE 16384-point scene of the same generator, single thread."""
@@ -276,6 +289,7 @@ def main():
             "roofline": roof, "kernels": kernels, "fps": fps,
             "nms": {"ms_9000_to_100": round(nms_ms, 4), "kept": nms_keep, "pairs": 9000 * 8999 // 2,
                     "metric": "rotated-NMS ms @9k boxes"},
+            "fps_dense": time_fps_dense(device),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(store)

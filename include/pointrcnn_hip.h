@@ -54,9 +54,12 @@ const char *prcnn_last_hip_error_string(void);
  * inp (b,n,3) -> out (b,m) int32.  out[:,0]=0; m-1 greedy iterations with the
  * reference's fp32 distance (no FMA contraction) and tie-break (max value, then
  * smallest k mod 512, then smallest k).  `temp` is the reference's scratch argument
- * (32*n floats there): here it is only touched when n > 32768 (clouds too large for
- * one CU's registers + LDS) and must then hold prcnn_fps_temp_bytes(b,n) bytes; it
- * may be NULL otherwise. */
+ * (32*n floats there).  Here clouds of up to 16384 points never touch it (it may be NULL);
+ * larger clouds are split over several cooperating workgroups that exchange one 8-byte
+ * record per iteration through `temp`, which must then hold prcnn_fps_temp_bytes(b,n)
+ * bytes (it is zeroed by the call; its first int is an error word that stays 0 unless a
+ * bounded wait timed out).  With temp == NULL clouds up to 32768 points run on one CU with
+ * the min-distance array in LDS; beyond that PRCNN_WORKSPACE is returned. */
 int prcnn_farthest_point_sample(int b, int n, int m, const float *inp, float *temp,
                                 int *out, prcnn_stream_t stream);
 size_t prcnn_fps_temp_bytes(int b, int n);

@@ -130,62 +130,123 @@ __global__ __launch_bounds__(512 * H) void fps_kernel(int n, int m,
     }
 }
 
-// Clouds that do not fit one CU (n > 32768): same algorithm with the running
-// min-distance array in the caller's `temp` buffer (the reference's scratch argument,
-// tf_sampling.cpp:114-117) and the points re-read through L2 each iteration.
-__global__ __launch_bounds__(1024) void fps_global_kernel(int b, int n, int m,
-                                                           const float *__restrict__ dataset,
-                                                           float *__restrict__ temp,
-                                                           int *__restrict__ idxs)
+// Clouds that do not fit one CU (n > 16384): G workgroups per cloud, each holding a
+// 16384-point slice in registers exactly as above.  Per iteration every workgroup
+// publishes its best candidate as ONE 8-byte data-tagged granule
+//   [63:32] value bits + 1   [31:15] ~(k mod 512, k / 512)   [14:0] iteration tag
+// with a single agent-scope (sc1, write-through) store and polls the G granules of its
+// cloud with agent-scope loads until every tag equals the iteration: no counters, no
+// resets, no fences (an 8-byte granule written by one store is never observed torn; the
+// tag makes a stale value unmistakable).  The granule array (part of `temp`) is zeroed by
+// a hipMemsetAsync ahead of the launch; tag 0 is never used before the slot has been
+// overwritten.  All G workgroups of a cloud must be resident together: the host keeps the
+// grid <= 256 workgroups (one 1024-thread workgroup per CU) and every spin is bounded
+// (on time-out the error word in `temp` is set and the kernel leaves).
+constexpr int COOP_PPT = 16;
+constexpr int COOP_SLICE = 1024 * COOP_PPT;
+
+__global__ __launch_bounds__(1024) void fps_coop_kernel(int n, int m, int G, int cloud0,
+                                                        const float *__restrict__ dataset,
+                                                        unsigned long long *__restrict__ gran,
+                                                        int *__restrict__ err,
+                                                        int *__restrict__ idxs)
 {
-    constexpr int T = 1024, NW = 16;
-    __shared__ int rec[2 * NW * 2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int PPT = COOP_PPT, P2 = PPT / 2;
+    __shared__ unsigned long long slot[3];
+    __shared__ unsigned long long bcast[2];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
     const int s = tid & 511, h = tid >> 9;
-    for (int i = blockIdx.x; i < b; i += gridDim.x) {
-        const float *data = dataset + (size_t)i * n * 3;
-        int *tdg = reinterpret_cast<int *>(temp) + (size_t)blockIdx.x * n;
-        int *out = idxs + (size_t)i * m;
-        for (int k = tid; k < n; k += T) tdg[k] = f2i(1e38f);
-        int old = 0;
-        if (tid == 0) out[0] = 0;
-        // lane (s,h) walks k = s + 512*(2*r + h): ascending k inside one reference slot.
-        for (int j = 1; j < m; ++j) {
-            const int so = __builtin_amdgcn_readfirstlane(old);
-            const float x1 = data[so * 3 + 0], y1 = data[so * 3 + 1], z1 = data[so * 3 + 2];
-            int best = f2i(-1.0f), bk = 0;
-            for (int k = s + 512 * h; k < n; k += T) {
-                const float dx = data[k * 3 + 0] - x1, dy = data[k * 3 + 1] - y1,
-                            dz = data[k * 3 + 2] - z1;
-                const float d = dx * dx + dy * dy + dz * dz;
-                const int t0 = tdg[k];
-                const int d2 = min(f2i(d), t0);
-                if (d2 != t0) tdg[k] = d2;
-                bk = d2 > best ? k : bk;
+    const int cloud = cloud0 + blockIdx.x / G;
+    const int g = blockIdx.x % G;
+    const int base = g * COOP_SLICE;
+    const float *data = dataset + (size_t)cloud * n * 3;
+    int *out = idxs + (size_t)cloud * m;
+    // two granule sets by iteration parity: a fast workgroup may publish iteration j+1 while a
+    // slow one still reads iteration j (it cannot get two ahead: j+1 needs everyone's j+1)
+    unsigned long long *cgran = gran + (size_t)cloud * 2 * G;
+
+    f32x2 px[P2], py[P2], pz[P2];
+    int td[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        const int k = base + s + 512 * (h * PPT + q);
+        const bool ok = k < n;
+        px[q >> 1][q & 1] = ok ? data[k * 3 + 0] : 0.f;
+        py[q >> 1][q & 1] = ok ? data[k * 3 + 1] : 0.f;
+        pz[q >> 1][q & 1] = ok ? data[k * 3 + 2] : 0.f;
+        td[q] = ok ? f2i(1e38f) : f2i(-1.0f);
+    }
+    if (tid < 3) slot[tid] = 0ull;
+    if (tid == 0 && g == 0) out[0] = 0;
+    int old = 0;
+    __syncthreads();
+
+    for (int j = 1; j < m; ++j) {
+        const int so = __builtin_amdgcn_readfirstlane(old);
+        const float x1 = data[so * 3 + 0], y1 = data[so * 3 + 1], z1 = data[so * 3 + 2];
+        int best = f2i(-1.0f), bq = 0;
+#pragma unroll
+        for (int p = 0; p < P2; ++p) {
+            const f32x2 dx = px[p] - x1, dy = py[p] - y1, dz = pz[p] - z1;
+            const f32x2 d = dx * dx + dy * dy + dz * dz;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = 2 * p + u;
+                const int d2 = min(f2i(d[u]), td[q]);
+                td[q] = d2;
+                bq = d2 > best ? q : bq;
                 best = max(best, d2);
             }
-            // lanes of one wave share h, so lane order = slot order; the two halves
-            // (h=0,1) of a slot interleave in k, which the (k mod 512, k/512) key resolves.
-            const int wmax = wave_max_i32(best);
-            const unsigned long long eq = __ballot(best == wmax);
-            const int first = __builtin_ctzll(eq);
-            const int wk = __builtin_amdgcn_readlane(bk, first);
-            const int par = j & 1;
+        }
+        const int bk = best > f2i(-1.0f) ? base + s + 512 * (h * PPT + bq) : 0;
+        const int wmax = wave_max_i32(best);
+        const unsigned long long eq = __ballot(best == wmax);
+        const int wk = __builtin_amdgcn_readlane(bk, __builtin_ctzll(eq));
+        const int cur = j % 3;
+        if (lane == 0)
+            atomicMax(&slot[cur], fps_pack(wmax, (unsigned)(((wk & 511) << 8) | (wk >> 9))));
+        __syncthreads();
+        if (wave == 0) {
+            const unsigned long long mine = slot[cur];                  // (value+1 | 0, ~key32)
+            const unsigned tag = (unsigned)j & 0x7fffu;
             if (lane == 0) {
-                rec[(par * NW + wave) * 2 + 0] = wmax;
-                rec[(par * NW + wave) * 2 + 1] = wk;
+                const unsigned long long v = (mine & 0xffffffff00000000ull) |
+                                             ((mine & 0x1ffffull) << 15) | tag;
+                __hip_atomic_store(&cgran[(j & 1) * G + g], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            __syncthreads();
-            const int e = lane < NW ? lane : 0;
-            const int ev = rec[(par * NW + e) * 2 + 0];
-            const int ek = rec[(par * NW + e) * 2 + 1];
-            const int mv = row16_allmax_i32(ev);
-            const unsigned key = ev == mv ? (unsigned)(((ek & 511) << 8) | (ek >> 9)) : 0x7fffffffu;
-            const unsigned mk = row16_allmin_u32(key);
-            old = __builtin_amdgcn_readfirstlane((int)((mk >> 8) + ((mk & 255u) << 9)));
-            if (tid == 0) out[j] = old;
+            unsigned long long v = 0ull;
+            int spins = 0;
+            bool timeout = false;
+            for (;;) {
+                if (lane < G)
+                    v = __hip_atomic_load(&cgran[(j & 1) * G + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ready = lane >= G || ((unsigned)v & 0x7fffu) == tag;
+                if (__all(ready)) break;
+                if (++spins > (1 << 22)) { timeout = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (timeout) {
+                if (lane == 0) { atomicExch(err, 1); bcast[j & 1] = ~0ull; }
+            } else {
+                // max over the G granules of (value, ~key): drop the tag, then a 64-bit butterfly
+                unsigned long long w = lane < G ? (v >> 15) : 0ull;
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    const unsigned long long o = __shfl_xor(w, off);
+                    w = o > w ? o : w;
+                }
+                if (lane == 0) bcast[j & 1] = w;
+            }
         }
         __syncthreads();
+        const unsigned long long win = bcast[j & 1];
+        if (win == ~0ull) return;                                        // time-out: leave (uniform)
+        if (tid == 0) slot[(j + 2) % 3] = 0ull;
+        const unsigned k2 = ~(unsigned)win & 0x1ffffu;
+        old = (int)((k2 >> 8) + ((k2 & 255u) << 9));
+        if (tid == 0 && g == 0) out[j] = old;
     }
 }
 
@@ -221,8 +282,9 @@ static int launch_fps(int b, int n, int m, const float *inp, int *out, hipStream
 
 extern "C" size_t prcnn_fps_temp_bytes(int b, int n)
 {
-    if (n <= 32768 || b <= 0) return 0;
-    return sizeof(float) * (size_t)n * (size_t)(b < 32 ? b : 32);
+    if (n <= 16384 || b <= 0) return 0;
+    const size_t G = ((size_t)n + prcnn::COOP_SLICE - 1) / prcnn::COOP_SLICE;
+    return 256 + (((size_t)b * 2 * G * sizeof(unsigned long long) + 255) & ~(size_t)255);
 }
 
 extern "C" int prcnn_farthest_point_sample(int b, int n, int m, const float *inp, float *temp,
@@ -241,11 +303,21 @@ extern "C" int prcnn_farthest_point_sample(int b, int n, int m, const float *inp
     if (n <= 4096) return launch_fps<4, 2, false>(b, n, m, inp, out, st);
     if (n <= 8192) return launch_fps<8, 2, false>(b, n, m, inp, out, st);
     if (n <= 16384) return launch_fps<16, 2, false>(b, n, m, inp, out, st);
-    if (n <= 32768) return launch_fps<32, 2, true>(b, n, m, inp, out, st);
-    if (!temp) return PRCNN_WORKSPACE;
-    hipLaunchKernelGGL(fps_global_kernel, dim3(b < 32 ? b : 32), dim3(1024), 0, st, b, n, m, inp,
-                       temp, out);
-    PRCNN_LAUNCH_CHECK();
+    // without a workspace a cloud of up to 32768 points still fits one CU (min distances in LDS)
+    if (!temp) return n <= 32768 ? launch_fps<32, 2, true>(b, n, m, inp, out, st) : PRCNN_WORKSPACE;
+    if (m > 32767 * 2) return PRCNN_UNSUPPORTED;      // 15-bit iteration tag must not alias within reach
+    // cooperative path: temp = [error word (256 B)] [b * 2 * G granules]
+    const int G = (n + COOP_SLICE - 1) / COOP_SLICE;
+    const size_t bytes = prcnn_fps_temp_bytes(b, n);
+    if (hipMemsetAsync(temp, 0, bytes, st) != hipSuccess) return PRCNN_HIP_ERROR;
+    int *err = reinterpret_cast<int *>(temp);
+    unsigned long long *gran = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(temp) + 256);
+    const int per_launch = 256 / G;                   // clouds whose workgroups are co-resident
+    for (int c0 = 0; c0 < b; c0 += per_launch) {
+        const int nc = b - c0 < per_launch ? b - c0 : per_launch;
+        hipLaunchKernelGGL(fps_coop_kernel, dim3(nc * G), dim3(1024), 0, st, n, m, G, c0, inp, gran, err, out);
+        PRCNN_LAUNCH_CHECK();
+    }
     return PRCNN_OK;
 }
 

@@ -18,6 +18,7 @@
 // lane's A operands of a whole chunk are 8 contiguous floats (2 x ds_read_b128);
 // A rows are padded to 20 floats (conflict-free b128 reads), B is [k][BN] (conflict-free
 // b32 reads).
+#include <stdlib.h>
 #include "common.h"
 
 namespace prcnn {
@@ -347,10 +348,26 @@ static int launch_mlp(const MlpArgs &a, hipStream_t st)
 {
     const long long rb = (a.rows + BM - 1) / BM;
     if (rb > 0x7fffffffLL) return PRCNN_UNSUPPORTED;
-    if (a.cout <= 32) {
+    // tile width: as wide as cout allows, but narrower when the grid would leave most of
+    // the 256 CUs (x3 resident workgroups) without work
+    // Tile width, from the batch-16 sweep in profiles/r01_mlp_tile_sweep.txt: 128 columns
+    // amortise the A staging best when K is large or the grid is many rounds deep; 64 columns
+    // (4 waves/SIMD instead of 3, twice the workgroups) win on shallow grids; never pad a
+    // narrow layer up to a wide tile.
+    int bn;
+    const long long wgs128 = rb * ((a.cout + 127) / 128);
+    if (a.cout <= 32) bn = 32;
+    else if (a.cout <= 64) bn = 64;
+    else if (a.cout <= 96) bn = rb >= 2048 ? 32 : 64;
+    else if (wgs128 < 256) bn = rb * ((a.cout + 63) / 64) < 256 ? 32 : 64;
+    else if (a.cin >= 512) bn = 128;
+    else if (wgs128 <= 1024) bn = 64;
+    else bn = 128;
+    if (const char *f = getenv("PRCNN_MLP_BN")) bn = atoi(f);   // tuning aid (32 / 64 / 128)
+    if (bn == 32) {
         dim3 grid((unsigned)rb, (a.cout + 31) / 32);
         hipLaunchKernelGGL((mlp_kernel<4, 1, 1, 1, GATHER, BF16>), grid, dim3(MLP_THREADS), 0, st, a);
-    } else if (a.cout <= 64) {
+    } else if (bn == 64) {
         dim3 grid((unsigned)rb, (a.cout + 63) / 64);
         hipLaunchKernelGGL((mlp_kernel<4, 1, 1, 2, GATHER, BF16>), grid, dim3(MLP_THREADS), 0, st, a);
     } else {

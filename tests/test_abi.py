@@ -31,7 +31,7 @@ def test_python_binding_covers_the_header():
     assert L.prcnn_status_string(0) == b"ok"
     assert L.prcnn_nms_rotate_workspace_bytes(9000) > 9000 * 141 * 8
     assert L.prcnn_fps_temp_bytes(4, 16384) == 0
-    assert L.prcnn_fps_temp_bytes(4, 131072) == 4 * 131072 * 4
+    assert L.prcnn_fps_temp_bytes(4, 131072) == 256 + 4 * 2 * 8 * 8
 
 
 def test_argument_checks_need_no_gpu():

@@ -62,6 +62,20 @@ def test_fps_lds_and_global_paths(cuda):
     assert got[0] == 0 and got.min() >= 0 and got.max() < 131072 and len(set(got.tolist())) == 2048
 
 
+def test_fps_single_cu_lds_path_without_workspace(cuda):
+    """temp == NULL: clouds of 16385..32768 points run on one CU with the min distances in LDS."""
+    from pointrcnn_amd import _lib
+    pts = S.dense_scene(9, 20000)[None, :, :3].copy()
+    t = dev(pts, cuda)
+    out = torch.empty((1, 200), dtype=torch.int32, device=cuda)
+    rc = _lib.lib().prcnn_farthest_point_sample(1, 20000, 200, t.data_ptr(), None, out.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert np.array_equal(npy(out), O.farthest_point_sample(200, pts))
+    rc = _lib.lib().prcnn_farthest_point_sample(1, 40000, 8, t.data_ptr(), None, out.data_ptr(), None)
+    assert rc == -4                      # PRCNN_WORKSPACE: larger clouds need `temp`
+
+
 def test_fps_errors(cuda):
     x = torch.zeros((1, 8, 3), device=cuda)
     with pytest.raises(ValueError):

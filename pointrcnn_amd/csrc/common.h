@@ -30,12 +30,15 @@ __device__ __forceinline__ int dpp_i32(int old, int v)
 }
 
 // all-reduce inside each row of 16 lanes: xor1, xor2 (quad_perm), half-mirror, mirror
+// `old` = INT_MIN is the identity of max, so lanes a DPP control leaves unwritten contribute
+// nothing and the compiler can fold each move into a single v_max_i32_dpp.
 __device__ __forceinline__ int row16_allmax_i32(int v)
 {
-    v = max(v, dpp_i32<0xB1>(v, v));   // quad_perm [1,0,3,2]
-    v = max(v, dpp_i32<0x4E>(v, v));   // quad_perm [2,3,0,1]
-    v = max(v, dpp_i32<0x141>(v, v));  // row_half_mirror
-    v = max(v, dpp_i32<0x140>(v, v));  // row_mirror
+    constexpr int ID = (int)0x80000000;
+    v = max(v, dpp_i32<0xB1>(ID, v));   // quad_perm [1,0,3,2]
+    v = max(v, dpp_i32<0x4E>(ID, v));   // quad_perm [2,3,0,1]
+    v = max(v, dpp_i32<0x141>(ID, v));  // row_half_mirror
+    v = max(v, dpp_i32<0x140>(ID, v));  // row_mirror
     return v;
 }
 __device__ __forceinline__ unsigned row16_allmin_u32(unsigned v)
@@ -49,9 +52,10 @@ __device__ __forceinline__ unsigned row16_allmin_u32(unsigned v)
 // wave-wide max of a signed int; result is wave-uniform (SGPR)
 __device__ __forceinline__ int wave_max_i32(int v)
 {
+    constexpr int ID = (int)0x80000000;
     v = row16_allmax_i32(v);
-    v = max(v, dpp_i32<0x142, 0xA>(v, v));  // row_bcast:15 into rows 1,3
-    v = max(v, dpp_i32<0x143, 0xC>(v, v));  // row_bcast:31 into rows 2,3
+    v = max(v, dpp_i32<0x142, 0xA>(ID, v));  // row_bcast:15 into rows 1,3
+    v = max(v, dpp_i32<0x143, 0xC>(ID, v));  // row_bcast:31 into rows 2,3
     return __builtin_amdgcn_readlane(v, 63);
 }
 

@@ -76,8 +76,9 @@ int prcnn_gather_point(int b, int n, int m, const float *inp, const int *idx, fl
  *   tf_grouping.cpp:66, tf_grouping_g.cu:3-36,125-128.
  * xyz1 (b,n,3) points, xyz2 (b,m,3) centroids -> idx (b,m,nsample), pts_cnt (b,m).
  * First `nsample` points in INDEX ORDER with max(sqrtf(d2),1e-20f) < radius; rows are
- * padded with the first hit; rows without any hit are left unwritten (as the
- * reference leaves them) and get pts_cnt 0.  pts_cnt may be NULL. */
+ * padded with the first hit.  Rows without any hit get pts_cnt 0 and are ZERO-FILLED (the
+ * reference leaves them uninitialised, tf_grouping_g.cu:26-34; zero is what its callers
+ * read from freshly cleared memory).  pts_cnt may be NULL. */
 int prcnn_query_ball_point(int b, int n, int m, float radius, int nsample,
                            const float *xyz1, const float *xyz2, int *idx, int *pts_cnt,
                            prcnn_stream_t stream);

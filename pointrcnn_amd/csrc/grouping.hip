@@ -120,7 +120,7 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(int n, int m, co
         if (__syncthreads_and(done)) break;
     }
     // pad rows that found fewer than nsample points with the first hit
-    // (tf_grouping_g.cu:26-29); rows without any hit stay unwritten.
+    // (tf_grouping_g.cu:26-29); rows without any hit are zero-filled.
 #pragma unroll
     for (int c = 0; c < BQ_CPW; ++c) {
         const int j = j0 + c;
@@ -130,8 +130,10 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(int n, int m, co
                 const int ns = sc.nsample[s];
                 const int cc = min(cnt[c][s], ns);
                 int *row = sc.idx[s] + ((size_t)bi * m + j) * ns;
-                if (cc > 0)
-                    for (int l = cc + lane; l < ns; l += 64) row[l] = first[c][s];
+                // no hit at all: the reference leaves the row uninitialised; write zeros so the
+                // result is deterministic (and callers need not pre-clear idx)
+                const int fill = cc > 0 ? first[c][s] : 0;
+                for (int l = cc + lane; l < ns; l += 64) row[l] = fill;
                 if (sc.pts_cnt[s] && lane == 0) sc.pts_cnt[s][(size_t)bi * m + j] = cc;
             }
         }

@@ -112,13 +112,13 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
 
 // ---- kernel ---------------------------------------------------------------------------
 // WM x WN waves (WM*WN == 4), each wave owns TM x TN MFMA tiles of 32x32.
-template <int WM, int WN, int TM, int TN, bool GATHER, bool BF16>
+template <int WM, int WN, int TM, int TN, bool GATHER, bool BF16, int KB>
 __global__ __launch_bounds__(MLP_THREADS) void mlp_kernel(const MlpArgs a)
 {
     constexpr int BN = WN * TN * 32;
-    constexpr int BK = BF16 ? 32 : 16;
+    constexpr int BK = BF16 ? 32 : KB;             // fp32: 16 (narrow inputs) or 32
     // LDS row strides (in 4-byte words): fp32 A rows 16 -> 20; bf16 A rows 32 bf16 = 16 words -> 20
-    constexpr int AS = 20;
+    constexpr int AS = BF16 ? 20 : BK + 4;          // both conflict-free for ds_read_b128
     constexpr int A_WORDS = BM * AS;
     // B: fp32 [BK][BN] words; bf16 transposed [BN][BK] bf16 = [BN][16 words] -> stride 20
     constexpr int B_WORDS = BF16 ? BN * AS : BK * BN;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_kernel(const MlpArgs a)
 
     // ---- staging assignment -------------------------------------------------------------
     // A: BM x BK elements; thread -> (row = tid/2, half = tid&1): BK/2 consecutive k
-    constexpr int A_PER = BK / 2;                    // 8 (fp32) or 16 (bf16) elements
+    constexpr int A_PER = BK / 2;                    // elements per thread
     const int arow = tid >> 1, ahalf = tid & 1;
     const RowSrc rs = make_row<GATHER>(a, row0 + arow);
     const bool a_vec = GATHER ? ((a.c & 3) == 0 && (((uintptr_t)a.feats) & 15) == 0)
@@ -218,19 +218,20 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_kernel(const MlpArgs a)
         __syncthreads();
         if (ch + 1 < nchunks) load_chunk((ch + 1) * BK);
         if (!BF16) {
-            f32x4 af[TM][2];
+            constexpr int KS = BK / 2;                   // MFMA steps per chunk; phys k = kh*KS + s
+            f32x4 af[TM][KS / 4];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const unsigned *p = &As[((wm * TM + i) * 32 + li) * AS + kh * 8];
-                af[i][0] = *reinterpret_cast<const f32x4 *>(p);
-                af[i][1] = *reinterpret_cast<const f32x4 *>(p + 4);
+                const unsigned *p = &As[((wm * TM + i) * 32 + li) * AS + kh * KS];
+#pragma unroll
+                for (int v = 0; v < KS / 4; ++v) af[i][v] = *reinterpret_cast<const f32x4 *>(p + 4 * v);
             }
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
+            for (int s = 0; s < KS; ++s) {
                 float bf[TN];
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    bf[j] = __builtin_bit_cast(float, Bs[(kh * 8 + s) * BN + (wn * TN + j) * 32 + li]);
+                    bf[j] = __builtin_bit_cast(float, Bs[(kh * KS + s) * BN + (wn * TN + j) * 32 + li]);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -364,16 +365,17 @@ static int launch_mlp(const MlpArgs &a, hipStream_t st)
     else if (wgs128 <= 1024) bn = 64;
     else bn = 128;
     if (const char *f = getenv("PRCNN_MLP_BN")) bn = atoi(f);   // tuning aid (32 / 64 / 128)
-    if (bn == 32) {
-        dim3 grid((unsigned)rb, (a.cout + 31) / 32);
-        hipLaunchKernelGGL((mlp_kernel<4, 1, 1, 1, GATHER, BF16>), grid, dim3(MLP_THREADS), 0, st, a);
-    } else if (bn == 64) {
-        dim3 grid((unsigned)rb, (a.cout + 63) / 64);
-        hipLaunchKernelGGL((mlp_kernel<4, 1, 1, 2, GATHER, BF16>), grid, dim3(MLP_THREADS), 0, st, a);
-    } else {
-        dim3 grid((unsigned)rb, (a.cout + 127) / 128);
-        hipLaunchKernelGGL((mlp_kernel<2, 2, 2, 2, GATHER, BF16>), grid, dim3(MLP_THREADS), 0, st, a);
-    }
+    // measured (profiles/r01_mlp_tile_sweep.txt): 32-deep fp32 chunks do not pay (the kernel is
+    // MFMA-issue bound, not barrier bound), so fp32 stays at 16
+    int kb = BF16 ? 32 : 16;
+    if (const char *f = getenv("PRCNN_MLP_KB")) kb = atoi(f);   // tuning aid (16 / 32)
+    dim3 grid((unsigned)rb, (a.cout + bn - 1) / bn);
+#define PRCNN_MLP_LAUNCH(WM_, WN_, TM_, TN_, KB_) \
+    hipLaunchKernelGGL((mlp_kernel<WM_, WN_, TM_, TN_, GATHER, BF16, KB_>), grid, dim3(MLP_THREADS), 0, st, a)
+    if (bn == 32) { if (kb == 16) PRCNN_MLP_LAUNCH(4, 1, 1, 1, 16); else PRCNN_MLP_LAUNCH(4, 1, 1, 1, 32); }
+    else if (bn == 64) { if (kb == 16) PRCNN_MLP_LAUNCH(4, 1, 1, 2, 16); else PRCNN_MLP_LAUNCH(4, 1, 1, 2, 32); }
+    else { if (kb == 16) PRCNN_MLP_LAUNCH(2, 2, 2, 2, 16); else PRCNN_MLP_LAUNCH(2, 2, 2, 2, 32); }
+#undef PRCNN_MLP_LAUNCH
     PRCNN_LAUNCH_CHECK();
     return PRCNN_OK;
 }

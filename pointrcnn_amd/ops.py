@@ -126,8 +126,8 @@ def gather_point(inp, idx):
 
 def query_ball_point(radius, nsample, xyz1, xyz2):
     """tf_grouping.py:9-21.  xyz1 (b,n,3) points, xyz2 (b,m,3) queries ->
-    idx (b,m,nsample) int32, pts_cnt (b,m) int32.  idx is zero-initialised, so the rows
-    the reference leaves unwritten (no point in the ball) read 0."""
+    idx (b,m,nsample) int32, pts_cnt (b,m) int32.  Rows the reference leaves unwritten
+    (no point in the ball) are zero-filled by the kernel."""
     xyz1 = _dev(xyz1, torch.float32, "QueryBallPoint xyz1", 3, 3)      # tf_grouping.cpp:79
     xyz2 = _dev(xyz2, torch.float32, "QueryBallPoint xyz2", 3, 3)      # tf_grouping.cpp:84
     if xyz1.shape[0] != xyz2.shape[0]:
@@ -135,7 +135,7 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     b, n, _ = xyz1.shape
     m = xyz2.shape[1]
     nsample = int(nsample)
-    idx = torch.zeros((b, m, max(nsample, 0)), dtype=torch.int32, device=xyz1.device)
+    idx = torch.empty((b, m, max(nsample, 0)), dtype=torch.int32, device=xyz1.device)
     cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
     _lib.check(_run("query_ball_point", {"tests": b * m * n, "bytes": b * (12 * n + 12 * m + 4 * m * nsample + 4 * m)},
                     lambda: _lib.lib().prcnn_query_ball_point(b, n, m, float(radius), nsample, _p(xyz1), _p(xyz2),
@@ -156,7 +156,7 @@ def query_ball_point_msg(radius_list, nsample_list, xyz1, xyz2):
     k = len(radius_list)
     if k > 4:
         return [query_ball_point(r, ns, xyz1, xyz2) for r, ns in zip(radius_list, nsample_list)]
-    res = [(torch.zeros((b, m, max(int(ns), 0)), dtype=torch.int32, device=xyz1.device),
+    res = [(torch.empty((b, m, max(int(ns), 0)), dtype=torch.int32, device=xyz1.device),
             torch.empty((b, m), dtype=torch.int32, device=xyz1.device)) for ns in nsample_list]
     radii = (ctypes.c_float * k)(*[float(r) for r in radius_list])
     nss = (ctypes.c_int * k)(*[int(ns) for ns in nsample_list])

@@ -72,7 +72,8 @@ def rpn_sa_fp_stack(point_cloud, params=None, precision=None, is_training=False,
                             scope='fa_layer3', bn=True, params=params, precision=precision)
     l1 = pointnet_fp_module(xyzs[1], xyzs[2], feats[1], l2, RPN_FP[2], is_training, bn_decay,
                             scope='fa_layer4', bn=True, params=params, precision=precision)
-    p1 = torch.cat([l0_xyz, l0_points], dim=-1) if l0_points is not None else l0_xyz
+    # concat([l0_xyz, l0_points]) (models/rpn.py:191) is the input cloud itself
+    p1 = point_cloud.contiguous()
     l0 = pointnet_fp_module(l0_xyz, xyzs[1], p1, l1, RPN_FP[3], is_training, bn_decay,
                             scope='fa_layer5', bn=True, params=params, precision=precision)
     return l0, {"xyz": xyzs, "sa_feats": feats, "fp_feats": [l3, l2, l1, l0]}

@@ -181,6 +181,19 @@ int prcnn_sa_group_mlp_layer(int b, int n, int m, int nsample, int c, const floa
                              const float *shift, int relu, int pool, int precision,
                              float *out, int64_t ldo, prcnn_stream_t stream);
 
+/* A whole set-abstraction scale in one launch for NARROW layers: grouping + three shared-MLP
+ * layers + max over nsample (pointnet_util.py:177-192 for one radius; :43-53,116-126 for
+ * SSG), fp32 matrix cores, no intermediate activation in HBM.  Serves c+3 <= 8, c1,c2 <= 32,
+ * c3 <= 128, nsample 16 or 32 (e.g. the first RPN level, models/rpn.py:166-169); anything
+ * else returns PRCNN_UNSUPPORTED and the caller uses prcnn_sa_group_mlp_layer +
+ * prcnn_mlp_layer.  w_i are (cin_i, c_i) row-major; out (b*m, c3) rows at out + g*ldo. */
+int prcnn_sa_group_mlp3_pool(int b, int n, int m, int nsample, int c, const float *xyz,
+                             const float *feats, const float *new_xyz, const int *idx,
+                             int xyz_first, int c1, int c2, int c3, const float *w1,
+                             const float *s1, const float *t1, const float *w2, const float *s2,
+                             const float *t2, const float *w3, const float *s3, const float *t3,
+                             float *out, int64_t ldo, prcnn_stream_t stream);
+
 /* Max over consecutive groups of `nsample` rows, models/pointnet_util.py:126,192
  * (tf.reduce_max over the nsample axis) for group sizes the fused epilogue of
  * prcnn_mlp_layer does not cover (pool must there be 16, 32, 64 or 128).

@@ -325,3 +325,41 @@ def sa_group_mlp_layer(xyz, feats, new_xyz, idx, w, scale, shift, xyz_first=Fals
         _p(scale), _p(shift), int(relu), int(pool), int(precision), _p(out), cout, _stream())),
         "sa_group_mlp_layer")
     return out
+
+
+def sa_chain_supported(c, mlp, nsample, precision):
+    """Shapes the fully fused set-abstraction kernel serves (see prcnn_sa_group_mlp3_pool)."""
+    return (precision == PRECISION_FP32 and len(mlp) == 3 and c + 3 <= 8 and mlp[0] <= 32
+            and mlp[1] <= 32 and mlp[2] <= 128 and nsample in (16, 32))
+
+
+def sa_group_mlp3_pool(xyz, feats, new_xyz, idx, layers, xyz_first=False, out=None, out_col=0):
+    """Grouping + three shared-MLP layers + max over nsample in one launch (narrow layers).
+    layers = [(W, scale, shift)] * 3.  Returns (b, m, c3), or writes into out[..., out_col:]."""
+    xyz = _dev(xyz, torch.float32, "sa_group_mlp3_pool xyz", 3, 3)
+    new_xyz = _dev(new_xyz, torch.float32, "sa_group_mlp3_pool new_xyz", 3, 3)
+    idx = _dev(idx, torch.int32, "sa_group_mlp3_pool idx", 3)
+    b, n, _ = xyz.shape
+    _, m, ns = idx.shape
+    c = 0
+    if feats is not None:
+        feats = _dev(feats, torch.float32, "sa_group_mlp3_pool feats", 3)
+        c = feats.shape[2]
+    (W1, s1, t1), (W2, s2, t2), (W3, s3, t3) = [tuple(_dev(t, torch.float32, "layer") for t in L) for L in layers]
+    c1, c2, c3 = W1.shape[1], W2.shape[1], W3.shape[1]
+    if W1.shape[0] != c + 3 or W2.shape[0] != c1 or W3.shape[0] != c2:
+        raise ValueError("sa_group_mlp3_pool: layer shapes do not chain")
+    if out is None:
+        res = torch.empty((b, m, c3), dtype=torch.float32, device=xyz.device)
+        optr, ldo = res.data_ptr(), c3
+    else:
+        res, ldo, optr = out, out.shape[-1], out.data_ptr() + 4 * out_col
+    rows = b * m * ns
+    flops = 2 * rows * ((c + 3) * c1 + c1 * c2 + c2 * c3)
+    _lib.check(_run("sa_chain", {"shape": "rows%d K%d N%d-%d-%d pool%d" % (rows, c + 3, c1, c2, c3, ns),
+                                 "flops": flops, "bytes": rows * (4 + 4 * (c + 3)) + 4 * (rows // ns) * c3},
+                    lambda: _lib.lib().prcnn_sa_group_mlp3_pool(
+        b, n, m, ns, c, _p(xyz), _p(feats), _p(new_xyz), _p(idx), int(bool(xyz_first)), c1, c2, c3,
+        _p(W1), _p(s1), _p(t1), _p(W2), _p(s2), _p(t2), _p(W3), _p(s3), _p(t3), optr, ldo, _stream())),
+        "sa_group_mlp3_pool")
+    return res

@@ -153,6 +153,11 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
     if FUSED and (use_xyz or points is None) and nsample % 16 == 0 and 128 % nsample == 0:
         new_xyz = ops.gather_point(xyz, ops.farthest_point_sample(npoint, xyz))
         idx, _ = ops.query_ball_point(radius, nsample, xyz, new_xyz)
+        if ops.sa_chain_supported(c_feat, mlp, nsample, precision):
+            layers = [store.layer('%s/conv%d' % (scope, j), ci, co, bn)
+                      for j, (ci, co) in enumerate(zip([c_feat + 3] + list(mlp[:-1]), mlp))]
+            x = ops.sa_group_mlp3_pool(xyz, points, new_xyz, idx, layers, xyz_first=True)
+            return new_xyz, x, idx
         W, s, t = store.layer('%s/conv0' % scope, c_feat + 3, mlp[0], bn)
         x = ops.sa_group_mlp_layer(xyz, points, new_xyz, idx, W, s, t, xyz_first=True, relu=True,
                                    pool=nsample if len(mlp) == 1 else 1, precision=precision)
@@ -194,6 +199,13 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
         radius, nsample, mlp = radius_list[i], nsample_list[i], mlp_list[i]
         idx, pts_cnt = balls[i] if balls is not None else ops.query_ball_point(radius, nsample, xyz, new_xyz)
         fusable = FUSED and (use_xyz or points is None) and nsample % 16 == 0 and 128 % nsample == 0
+        if fusable and ops.sa_chain_supported(c_feat, mlp, nsample, precision):
+            # narrow layers: the whole scale (group, 3 layers, max-pool) is one kernel
+            layers = [store.layer('%s/conv%d_%d' % (scope, i, j), ci, co, bn)
+                      for j, (ci, co) in enumerate(zip([c_feat + 3] + list(mlp[:-1]), mlp))]
+            ops.sa_group_mlp3_pool(xyz, points, new_xyz, idx, layers, xyz_first=False, out=out, out_col=col)
+            col += mlp[-1]
+            continue
         if fusable:
             W, s, t = store.layer('%s/conv%d_0' % (scope, i), c_feat + 3, mlp[0], bn)
             x = ops.sa_group_mlp_layer(xyz, points, new_xyz, idx, W, s, t, xyz_first=False, relu=True,

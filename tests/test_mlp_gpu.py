@@ -91,6 +91,40 @@ def test_sa_group_mlp_layer_equals_materialised_path(cuda, prec, c, xyz_first, n
     close(got, O.max_pool(ref, ns), prec)
 
 
+@pytest.mark.parametrize("c,xyz_first,ns,mlp", [(1, False, 16, [16, 16, 32]), (1, False, 32, [32, 32, 64]),
+                                                 (0, True, 16, [20, 8, 100]), (4, True, 32, [32, 32, 128]),
+                                                 (5, False, 16, [7, 32, 33])])
+def test_sa_chain_kernel_equals_oracle_composition(cuda, c, xyz_first, ns, mlp):
+    """group + 3 layers + max-pool in one launch (prcnn_sa_group_mlp3_pool) vs the oracle's
+    op-by-op composition; odd group counts exercise the half-filled last tile."""
+    rng = np.random.default_rng(c * 7 + ns)
+    b, n, m = 2, 900, 37
+    xyz = rng.random((b, n, 3), dtype=np.float32)
+    feats = rng.standard_normal((b, n, c)).astype(np.float32) if c else None
+    new_xyz = O.gather_point(xyz, O.farthest_point_sample(m, xyz))
+    idx, _ = O.query_ball_point(0.3, ns, xyz, new_xyz)
+    layers, cin = [], c + 3
+    for co in mlp:
+        layers.append(rand_layer(rng, cin, co)); cin = co
+    gx = O.group_point(xyz, idx) - new_xyz[:, :, None, :]
+    g = gx if not c else np.concatenate([gx, O.group_point(feats, idx)] if xyz_first else [O.group_point(feats, idx), gx], -1)
+    for L in layers:
+        g = O.mlp_layer(g, *L)
+    ref = O.max_pool(g, ns)
+    assert ops.sa_chain_supported(c, mlp, ns, ops.PRECISION_FP32)
+    got = ops.sa_group_mlp3_pool(dev(xyz, cuda), None if feats is None else dev(feats, cuda), dev(new_xyz, cuda),
+                                 dev(idx, cuda), [tuple(dev(t, cuda) for t in L) for L in layers], xyz_first=xyz_first)
+    close(npy(got), ref, ops.PRECISION_FP32)
+    # writing into a column slice of a wider buffer leaves the rest untouched
+    buf = torch.full((b, m, mlp[-1] + 5), -3.0, device=cuda)
+    ops.sa_group_mlp3_pool(dev(xyz, cuda), None if feats is None else dev(feats, cuda), dev(new_xyz, cuda),
+                           dev(idx, cuda), [tuple(dev(t, cuda) for t in L) for L in layers], xyz_first=xyz_first,
+                           out=buf, out_col=2)
+    gb = npy(buf)
+    close(gb[:, :, 2:2 + mlp[-1]], ref, ops.PRECISION_FP32)
+    assert (gb[:, :, :2] == -3.0).all() and (gb[:, :, 2 + mlp[-1]:] == -3.0).all()
+
+
 def _oracle_sa_msg(xyz, points, npoint, radii, nsamples, mlps, layers):
     new_xyz = O.gather_point(xyz, O.farthest_point_sample(npoint, xyz))
     outs = []

@@ -78,6 +78,10 @@ def main():
             cin = c + 3
             W = [(torch.randn(ci, co, generator=rng).mul_(0.1).to(dev), torch.ones(co, device=dev), torch.zeros(co, device=dev))
                  for ci, co in zip([cin] + mlp[:-1], mlp)]
+            if want("mlp") and ops.sa_chain_supported(c, mlp, ns, a.precision):
+                us = timeit(lambda: ops.sa_group_mlp3_pool(x, f, new_xyz, idx, W), a.iters)
+                fl = 2 * b * m * ns * (cin * mlp[0] + mlp[0] * mlp[1] + mlp[1] * mlp[2])
+                rep("sa_chain (3 layers)", "rows%d K%d N%s" % (b * m * ns, cin, mlp), us, fl / us / 1e6 / 157.3, "%.1f TF" % (fl / us / 1e6))
             if want("mlp"):
                 us = timeit(lambda: ops.sa_group_mlp_layer(x, f, new_xyz, idx, *W[0], precision=a.precision), a.iters)
                 fl = 2 * b * m * ns * cin * mlp[0]

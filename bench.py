@@ -254,11 +254,19 @@ def main():
             traffic, tsrc = None, None
             # HBM bytes per launch from the committed PMC passes (profiles/, same kernel and shape)
             pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_hot_kernels.json")
-            if best["shape"] == "rows262144 K260 N128 pool1" and os.path.exists(pmc_path):
-                pm = json.load(open(pmc_path)).get("mlp_kernel<2, 2, 2, 2, false, false>")
-                if pm:
+            pmc_keys = {   # (kernel family, shape) -> entry of the PMC summary (tools/pmc_probe.py launches these shapes)
+                ("mlp_layer", "rows65536 K608 N256 pool1"): "mlp_kernel<2, 2, 2, 2, false, false, 16> grid_threads=262144",
+                ("mlp_layer", "rows262144 K260 N128 pool1"): "mlp_kernel<2, 2, 2, 2, false, false, 16> grid_threads=524288",
+                ("sa_chain", "rows2097152 K4 N32-32-64 pool32"): "sa_chain_kernel<4, 32, 32, 64>",
+            }
+            pk = pmc_keys.get((best["kernel"], best["shape"]))
+            if pk and precision == 0 and args.batch == BATCH and os.path.exists(pmc_path):
+                pm = json.load(open(pmc_path)).get(pk)
+                if pm and "hbm_bytes_corrected" in pm:
                     traffic = pm["hbm_bytes_corrected"]
-                    tsrc = "profiles/r01_pmc_hot_kernels.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, read side x2)"
+                    tsrc = ("profiles/r01_pmc_hot_kernels.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                            "tools/pmc_probe.py on this kernel and shape, read side x2 (gfx950); raw %d B"
+                            % int(pm["hbm_bytes_raw"]))
             roof = {"kernel": best["kernel"], "shape": best["shape"], "bound": best["bound"],
                     "achieved": round(best["achieved"], 3), "peak": best["peak"], "unit": best["unit"],
                     "frac": round(best["achieved"] / best["peak"], 4), "traffic": traffic,

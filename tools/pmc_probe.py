@@ -34,13 +34,21 @@ def main():
     x260 = torch.randn(b * 16384, 260, generator=g).to(dev)
     W260 = torch.randn(260, 128, generator=g).mul_(0.05).to(dev)
     W99 = torch.randn(99, 64, generator=g).mul_(0.1).to(dev)
+    x608 = torch.randn(b * 4096, 608, generator=g).to(dev)        # FP level 1, first layer: the step's most expensive launch
+    W608 = torch.randn(608, 256, generator=g).mul_(0.05).to(dev)
+    W4 = [(torch.randn(4, 32, generator=g).mul_(0.3).to(dev),) + (torch.ones(32, device=dev), torch.zeros(32, device=dev)),
+          (torch.randn(32, 32, generator=g).mul_(0.2).to(dev),) + (torch.ones(32, device=dev), torch.zeros(32, device=dev)),
+          (torch.randn(32, 64, generator=g).mul_(0.2).to(dev),) + (torch.ones(64, device=dev), torch.zeros(64, device=dev))]
+    (idx1, _), = ops.query_ball_point_msg([0.5], [32], xyz, new1)
     one = lambda c: (torch.ones(c, device=dev), torch.zeros(c, device=dev))
     torch.cuda.synchronize()
     work = {
         "group_point_kernel<4>": b * 1024 * 32 * (4 + 8 * 96),
         "three_interpolate_kernel<4>": b * 16384 * (24 + 16 * 256),
         "three_nn_interpolate_kernel<4>": b * (12 * 16384 + 12 * 4096) + b * 16384 * 16 * 256,
-        "mlp_kernel<2, 2, 2, 2, false, false>": 4 * (b * 16384 * 260 + 260 * 128 + b * 16384 * 128),
+        "mlp_kernel<2, 2, 2, 2, false, false> rows262144 K260 N128": 4 * (b * 16384 * 260 + 260 * 128 + b * 16384 * 128),
+        "mlp_kernel<2, 2, 2, 2, false, false> rows65536 K608 N256": 4 * (b * 4096 * 608 + 608 * 256 + b * 4096 * 256),
+        "sa_chain_kernel<4, 32, 32, 64> rows2097152": b * 4096 * 32 * (4 + 16) + 4 * b * 4096 * 64,
         "mlp_kernel<4, 1, 1, 2, true, false>": b * 1024 * 32 * (4 + 4 * 99) + 4 * b * 1024 * 32 * 64,
     }
     for _ in range(REPS):
@@ -48,6 +56,8 @@ def main():
         ops.three_interpolate(f256, i3, w)
         ops.three_nn_interpolate(xyz, new1, f256)
         ops.mlp_layer(x260, W260, *one(128))
+        ops.mlp_layer(x608, W608, *one(256))
+        ops.sa_group_mlp3_pool(xyz, feats, new1, idx1, W4)
         ops.sa_group_mlp_layer(new1, f1, new2, idx2, W99, *one(64))
         ops.query_ball_point_msg([0.1, 0.5], [16, 32], xyz, new1)
         ops.farthest_point_sample(4096, xyz)

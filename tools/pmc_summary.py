@@ -26,8 +26,18 @@ def short(name):
 def main():
     trace, fetch, write = sys.argv[1:4]
     res = {}
-    for r in rows(trace, "*kernel_trace.csv"):
+    def key(r):
         k = short(r["Kernel_Name"])
+        if k.startswith("mlp_kernel"):                  # several shapes share one instantiation
+            if "Grid_Size" in r:
+                g = int(r["Grid_Size"])
+            else:
+                g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+            k += " grid_threads=%d" % g
+        return k
+
+    for r in rows(trace, "*kernel_trace.csv"):
+        k = key(r)
         if "at::" in k or "rocclr" in k:
             continue
         d = res.setdefault(k, {"launches": 0, "ns": 0})
@@ -38,7 +48,7 @@ def main():
         for r in rows(dd, "*counter_collection.csv"):
             if r["Counter_Name"] != tag:
                 continue
-            k = short(r["Kernel_Name"])
+            k = key(r)
             a = acc.setdefault(k, [0, 0.0])
             a[0] += 1
             a[1] += float(r["Counter_Value"])

@@ -150,10 +150,36 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_kernel(const MlpArgs a)
     f32x4 areg[A_PER / 4];
     float breg[B_PER];
 
+    // Block-uniform fast-path conditions: an interior tile whose chunk lies wholly inside the
+    // vector-loadable part of A / B is fetched with unconditional 16-byte loads (no per-element
+    // predicates, no branches); everything else takes the general path.
+    const bool rows_full = row0 + BM <= a.rows;
+    const int a_klimit = GATHER ? (a.xyz_first ? 0 : a.c) : a.cin;     // A columns [0, a_klimit) are contiguous in memory
+    const bool a_fast = rows_full && a_vec;
+    const bool b_fast = b_vec && col0 + BN <= a.cout;
+    const float *a_base = (GATHER ? a.feats + rs.pi * a.c : a.x + rs.pi * a.ldx) + ahalf * A_PER;
+    const float *b_base = a.w + (size_t)bk * a.cout + col0 + bn;
+
     auto load_chunk = [&](int k0) {
+        if (a_fast && k0 + BK <= a_klimit) {
 #pragma unroll
-        for (int v = 0; v < A_PER / 4; ++v)
-            areg[v] = load_a4<GATHER>(a, rs, k0 + ahalf * A_PER + v * 4, a_vec);
+            for (int v = 0; v < A_PER / 4; ++v)
+                areg[v] = *reinterpret_cast<const f32x4 *>(a_base + k0 + v * 4);
+        } else {
+#pragma unroll
+            for (int v = 0; v < A_PER / 4; ++v)
+                areg[v] = load_a4<GATHER>(a, rs, k0 + ahalf * A_PER + v * 4, a_vec);
+        }
+        if (B_PER >= 4 && b_fast && k0 + BK <= a.cin) {
+            const float *wp = b_base + (size_t)k0 * a.cout;
+#pragma unroll
+            for (int v = 0; v < B_PER / 4; ++v) {
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(wp + v * 4);
+                breg[v * 4 + 0] = t[0]; breg[v * 4 + 1] = t[1];
+                breg[v * 4 + 2] = t[2]; breg[v * 4 + 3] = t[3];
+            }
+            return;
+        }
         const int k = k0 + bk;
         const bool kok = k < a.cin;
         const float *wrow = a.w + (size_t)(kok ? k : 0) * a.cout;

@@ -201,6 +201,41 @@ int prcnn_sa_group_mlp3_pool(int b, int n, int m, int nsample, int c, const floa
 int prcnn_max_pool(int64_t groups, int nsample, int c, const float *x, int64_t ldx, float *out,
                    int64_t ldo, prcnn_stream_t stream);
 
+/* ---- backward ops ------------------------------------------------
+ * All three are ordered segmented reductions: every output element is summed in exactly
+ * the order of the reference's serial CPU loops, so results are deterministic and equal
+ * to those loops bit for bit (the reference's GPU kernels use float atomicAdd, whose
+ * order varies).  The output needs no prior memset (the reference ops clear it first:
+ * tf_sampling.cpp:174, tf_grouping.cpp:204, tf_interpolate.cpp:258); every row is written.
+ * workspace: device memory of at least *_workspace_bytes(), 4-byte aligned, contents
+ * irrelevant on entry.  Indices outside [0, rows) are ignored. */
+
+/* scatteraddpointLauncher(b,n,m,out_g,idx,inp_g)  models/tf_ops/sampling/tf_sampling_g.cu:212-214
+ * (kernel :183-192; op GatherPointGrad tf_sampling.cpp:151-177).
+ * out_g (b,m,3), idx (b,m) -> inp_g (b,n,3):  inp_g[b,idx[b,j],:] += out_g[b,j,:]. */
+size_t prcnn_gather_point_grad_workspace_bytes(int b, int n, int m);
+int prcnn_gather_point_grad(int b, int n, int m, const float *out_g, const int *idx, float *inp_g,
+                            void *workspace, size_t workspace_bytes, prcnn_stream_t stream);
+
+/* groupPointGradLauncher(b,n,c,m,nsample,grad_out,idx,grad_points)
+ * models/tf_ops/grouping/tf_grouping.cpp:173 (kernel tf_grouping_g.cu:61-78, CPU twin
+ * group_point_grad_cpu query_ball_point.cpp:70-84).
+ * grad_out (b,m,nsample,c), idx (b,m,nsample) -> grad_points (b,n,c). */
+size_t prcnn_group_point_grad_workspace_bytes(int b, int n, int m, int nsample);
+int prcnn_group_point_grad(int b, int n, int c, int m, int nsample, const float *grad_out,
+                           const int *idx, float *grad_points, void *workspace,
+                           size_t workspace_bytes, prcnn_stream_t stream);
+
+/* threeinterpolate_grad_cpu(b,n,c,m,grad_out,idx,weight,grad_points)
+ * models/tf_ops/3d_interpolation/tf_interpolate.cpp:131-153 (standalone twin
+ * interpolate_grad_cpu interpolate.cpp:108-130).
+ * grad_out (b,n,c), idx (b,n,3), weight (b,n,3) -> grad_points (b,m,c):
+ * grad_points[b,idx[b,j,t],l] += grad_out[b,j,l]*weight[b,j,t], t = 0,1,2 in that order. */
+size_t prcnn_three_interpolate_grad_workspace_bytes(int b, int n, int m);
+int prcnn_three_interpolate_grad(int b, int n, int c, int m, const float *grad_out, const int *idx,
+                                 const float *weight, float *grad_points, void *workspace,
+                                 size_t workspace_bytes, prcnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

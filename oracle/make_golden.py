@@ -79,8 +79,36 @@ def main():
     np.savez_compressed(os.path.join(OUT, "fps_transcription.npz"), source="transcription",
                         cloud=cloud, idx_dup=idx_dup, tie=tie, idx_tie=idx_tie, small=small,
                         idx_small=idx_small)
+    grad_golden()
     print("golden vectors written to", os.path.normpath(OUT))
 
 
+def grad_golden():
+    """Backward ops: group_point_grad_cpu (query_ball_point.cpp:70-84) and
+    interpolate_grad_cpu (interpolate.cpp:108-130) on seeded inputs (own RNG stream, so the
+    forward fixtures above never change)."""
+    rng = np.random.default_rng(20251111)
+    b, n, m, ns, c = 2, 500, 60, 16, 9
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    idx[0, :, 3:] = idx[0, :, :1]                          # heavy rows: one point collects many entries
+    idx[1, 5] = 7
+    grad_out = rng.standard_normal((b, m, ns, c)).astype(np.float32)
+    gp = ref.group_point_grad_cpu(n, idx, grad_out)
+    b2, n2, m2, c2 = 2, 400, 50, 12
+    idx3 = rng.integers(0, m2, (b2, n2, 3)).astype(np.int32)
+    idx3[1, :, 1] = idx3[1, :, 0]                          # the same target twice within one point
+    w = rng.random((b2, n2, 3), dtype=np.float32)
+    w /= w.sum(-1, keepdims=True)
+    g3 = rng.standard_normal((b2, n2, c2)).astype(np.float32)
+    gi = ref.interpolate_grad_cpu(m2, idx3, w, g3)
+    np.savez_compressed(os.path.join(OUT, "grad_ref.npz"), source="reference", n=n, idx=idx,
+                        grad_out=grad_out, grad_points=gp, m3=m2, idx3=idx3, weight3=w, grad_out3=g3,
+                        grad_points3=gi)
+
+
 if __name__ == "__main__":
+    import sys
+    if "--grad-only" in sys.argv:
+        grad_golden()
+        raise SystemExit(0)
     main()

@@ -116,6 +116,37 @@ def three_interpolate(points, idx, weight):
     return out
 
 
+def gather_point_grad(inp, idx, out_g):
+    """Argument order of the reference op GatherPointGrad (tf_sampling.py:44-48): only
+    inp's shape is used."""
+    idx, out_g = _i32(idx), _f32(out_g)
+    b, n = inp.shape[0], inp.shape[1]
+    m = idx.shape[1]
+    g = np.empty((b, n, 3), np.float32)
+    lib().oracle_gather_point_grad(b, n, m, _p(out_g), _p(idx), _p(g))
+    return g
+
+
+def group_point_grad(points, idx, grad_out):
+    """GroupPointGrad (tf_grouping.py:43-47): only points' shape is used."""
+    idx, grad_out = _i32(idx), _f32(grad_out)
+    b, n, c = points.shape
+    _, m, ns = idx.shape
+    g = np.empty((b, n, c), np.float32)
+    lib().oracle_group_point_grad(b, n, c, m, ns, _p(grad_out), _p(idx), _p(g))
+    return g
+
+
+def three_interpolate_grad(points, idx, weight, grad_out):
+    """ThreeInterpolateGrad (tf_interpolate.py:30-35): only points' shape is used."""
+    idx, weight, grad_out = _i32(idx), _f32(weight), _f32(grad_out)
+    b, m, c = points.shape
+    n = idx.shape[1]
+    g = np.empty((b, m, c), np.float32)
+    lib().oracle_three_interpolate_grad(b, n, c, m, _p(grad_out), _p(idx), _p(weight), _p(g))
+    return g
+
+
 def rotated_intersection(b1, b2):
     b1 = np.ascontiguousarray(b1, np.float64)
     b2 = np.ascontiguousarray(b2, np.float64)

@@ -79,6 +79,27 @@ def interpolate_cpu(points, idx, weight):
     return out
 
 
+def group_point_grad_cpu(n, idx, grad_out):
+    """query_ball_point.cpp:70-84 (accumulates into a caller-cleared buffer)."""
+    idx = np.ascontiguousarray(idx, np.int32)
+    grad_out = np.ascontiguousarray(grad_out, np.float32)
+    b, m, ns, c = grad_out.shape
+    g = np.zeros((b, n, c), np.float32)
+    _grouping()._Z20group_point_grad_cpuiiiiiPKfPKiPf(b, n, c, m, ns, _p(grad_out), _p(idx), _p(g))
+    return g
+
+
+def interpolate_grad_cpu(m, idx, weight, grad_out):
+    """interpolate.cpp:108-130 (loop-identical to tf_interpolate.cpp:131-153)."""
+    idx = np.ascontiguousarray(idx, np.int32)
+    weight = np.ascontiguousarray(weight, np.float32)
+    grad_out = np.ascontiguousarray(grad_out, np.float32)
+    b, n, c = grad_out.shape
+    g = np.zeros((b, m, c), np.float32)
+    _interp()._Z20interpolate_grad_cpuiiiiPKfPKiS0_Pf(b, n, c, m, _p(grad_out), _p(idx), _p(weight), _p(g))
+    return g
+
+
 def threenn_origin_cpu(n, xyz2):
     """interpolate.cpp:21-64: the standalone twin whose distance is
     d = x2*x2+y2*y2+z2*z2 (:34) -- i.e. tf_interpolate.cpp:60-103 evaluated with

@@ -107,7 +107,7 @@ def farthest_point_sample(npoint, inp):
     return out
 
 
-def gather_point(inp, idx):
+def _gather_point_fwd(inp, idx):
     """tf_sampling.py:30-38.  inp (b,n,3), idx (b,m) -> (b,m,3)."""
     inp = _dev(inp, torch.float32, "GatherPoint inp", 3, 3)            # tf_sampling.cpp:131
     idx = _dev(idx, torch.int32, "GatherPoint idx", 2)                 # tf_sampling.cpp:135
@@ -169,7 +169,7 @@ def query_ball_point_msg(radius_list, nsample_list, xyz1, xyz2):
     return res
 
 
-def group_point(points, idx):
+def _group_point_fwd(points, idx):
     """tf_grouping.py:34-42.  points (b,n,c), idx (b,m,nsample) -> (b,m,nsample,c)."""
     points = _dev(points, torch.float32, "GroupPoint points", 3)       # tf_grouping.cpp:147
     idx = _dev(idx, torch.int32, "GroupPoint idx", 3)                  # tf_grouping.cpp:153
@@ -203,7 +203,7 @@ def three_nn(xyz1, xyz2):
     return dist, idx
 
 
-def three_interpolate(points, idx, weight):
+def _three_interpolate_fwd(points, idx, weight):
     """tf_interpolate.py:20-29.  points (b,m,c), idx/weight (b,n,3) -> (b,n,c)."""
     points = _dev(points, torch.float32, "ThreeInterpolate points", 3)          # :203
     idx = _dev(idx, torch.int32, "ThreeInterpolate idx", 3, 3)                  # :206
@@ -363,3 +363,145 @@ def sa_group_mlp3_pool(xyz, feats, new_xyz, idx, layers, xyz_first=False, out=No
         _p(W1), _p(s1), _p(t1), _p(W2), _p(s2), _p(t2), _p(W3), _p(s3), _p(t3), optr, ldo, _stream())),
         "sa_group_mlp3_pool")
     return res
+
+
+# ---- backward ops ----------------------------------------------------
+# Same argument lists as the reference's gradient ops (tf_sampling.py:44-48,
+# tf_grouping.py:43-47, tf_interpolate.py:30-35): the forward input comes first and only
+# its shape is used.  gather_point / group_point / three_interpolate route through the
+# autograd Functions below when their feature input requires grad, which is what
+# tf.RegisterGradient does in the reference.
+
+def _workspace(nbytes, device):
+    return torch.empty((max(int(nbytes), 4),), dtype=torch.uint8, device=device)
+
+
+def gather_point_grad(inp, idx, out_g):
+    """GatherPointGrad, tf_sampling.cpp:151-177.  inp (b,n,3) [shape only], idx (b,m),
+    out_g (b,m,3) -> inp_g (b,n,3)."""
+    idx = _dev(idx, torch.int32, "GatherPointGrad idx", 2)
+    out_g = _dev(out_g, torch.float32, "GatherPointGrad out_g", 3, 3)
+    if inp.dim() != 3 or inp.shape[2] != 3:
+        raise ValueError("GatherPointGradGpuOp expects (batch_size,num_points,3) inp")       # tf_sampling.cpp:156
+    b, n = int(inp.shape[0]), int(inp.shape[1])
+    m = idx.shape[1]
+    if idx.shape[0] != b or tuple(out_g.shape) != (b, m, 3):
+        raise ValueError("GatherPointGradGpuOp expects (batch_size,num_result) idx and (batch_size,num_result,3) out_g")
+    L = _lib.lib()
+    nb = L.prcnn_gather_point_grad_workspace_bytes(b, n, m)
+    ws = _workspace(nb, out_g.device)
+    inp_g = torch.empty((b, n, 3), dtype=torch.float32, device=out_g.device)
+    _lib.check(_run("gather_point_grad", {"bytes": b * m * 28 + b * n * 12},
+                    lambda: L.prcnn_gather_point_grad(b, n, m, _p(out_g), _p(idx), _p(inp_g), _p(ws), nb, _stream())),
+               "GatherPointGrad")
+    return inp_g
+
+
+def group_point_grad(points, idx, grad_out):
+    """GroupPointGrad, tf_grouping.cpp:174-207.  points (b,n,c) [shape only], idx (b,m,ns),
+    grad_out (b,m,ns,c) -> grad_points (b,n,c)."""
+    idx = _dev(idx, torch.int32, "GroupPointGrad idx", 3)
+    grad_out = _dev(grad_out, torch.float32, "GroupPointGrad grad_out", 4)
+    if points.dim() != 3:
+        raise ValueError("GroupPointGrad expects (batch_size, num_points, channel) points shape")   # :180
+    b, n, c = (int(v) for v in points.shape)
+    _, m, ns = idx.shape
+    if idx.shape[0] != b or tuple(grad_out.shape) != (b, m, ns, c):
+        raise ValueError("GroupPointGrad expects (b,m,nsample) idx and (b,m,nsample,c) grad_out")
+    L = _lib.lib()
+    nb = L.prcnn_group_point_grad_workspace_bytes(b, n, m, ns)
+    ws = _workspace(nb, grad_out.device)
+    g = torch.empty((b, n, c), dtype=torch.float32, device=grad_out.device)
+    _lib.check(_run("group_point_grad", {"bytes": b * m * ns * (4 + 4 * c) + b * n * c * 4},
+                    lambda: L.prcnn_group_point_grad(b, n, c, m, ns, _p(grad_out), _p(idx), _p(g), _p(ws), nb,
+                                                     _stream())),
+               "GroupPointGrad")
+    return g
+
+
+def three_interpolate_grad(points, idx, weight, grad_out):
+    """ThreeInterpolateGrad, tf_interpolate.cpp:225-261.  points (b,m,c) [shape only],
+    idx (b,n,3), weight (b,n,3), grad_out (b,n,c) -> grad_points (b,m,c)."""
+    idx = _dev(idx, torch.int32, "ThreeInterpolateGrad idx", 3, 3)
+    weight = _dev(weight, torch.float32, "ThreeInterpolateGrad weight", 3, 3)
+    grad_out = _dev(grad_out, torch.float32, "ThreeInterpolateGrad grad_out", 3)
+    if points.dim() != 3:
+        raise ValueError("ThreeInterpolateGrad expects (b,m,c) points shape")                    # :231
+    b, m, c = (int(v) for v in points.shape)
+    n = idx.shape[1]
+    if idx.shape[0] != b or tuple(weight.shape) != (b, n, 3) or tuple(grad_out.shape) != (b, n, c):
+        raise ValueError("ThreeInterpolateGrad expects (b,n,3) idx/weight and (b,n,c) grad_out")
+    L = _lib.lib()
+    nb = L.prcnn_three_interpolate_grad_workspace_bytes(b, n, m)
+    ws = _workspace(nb, grad_out.device)
+    g = torch.empty((b, m, c), dtype=torch.float32, device=grad_out.device)
+    _lib.check(_run("three_interpolate_grad", {"bytes": b * n * (24 + 12 * c) + b * m * c * 4},
+                    lambda: L.prcnn_three_interpolate_grad(b, n, c, m, _p(grad_out), _p(idx), _p(weight), _p(g),
+                                                           _p(ws), nb, _stream())),
+               "ThreeInterpolateGrad")
+    return g
+
+
+class _GatherPointFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, idx):
+        ctx.save_for_backward(idx)
+        ctx.inp_shape = inp.shape
+        return _gather_point_fwd(inp, idx)
+
+    @staticmethod
+    def backward(ctx, out_g):
+        (idx,) = ctx.saved_tensors
+        return gather_point_grad(torch.empty(ctx.inp_shape, device="meta"), idx, out_g), None
+
+
+class _GroupPointFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx):
+        ctx.save_for_backward(idx)
+        ctx.points_shape = points.shape
+        return _group_point_fwd(points, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        return group_point_grad(torch.empty(ctx.points_shape, device="meta"), idx, grad_out), None
+
+
+class _ThreeInterpolateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx, weight):
+        ctx.save_for_backward(idx, weight)
+        ctx.points_shape = points.shape
+        return _three_interpolate_fwd(points, idx, weight)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        return (three_interpolate_grad(torch.empty(ctx.points_shape, device="meta"), idx, weight, grad_out),
+                None, None)
+
+
+def _wants_grad(t):
+    return isinstance(t, torch.Tensor) and t.requires_grad and torch.is_grad_enabled()
+
+
+def gather_point(inp, idx):
+    """Differentiable front of _gather_point_fwd (same contract; see there)."""
+    if _wants_grad(inp):
+        return _GatherPointFn.apply(inp, idx)
+    return _gather_point_fwd(inp, idx)
+
+
+def group_point(points, idx):
+    """Differentiable front of _group_point_fwd (same contract; see there)."""
+    if _wants_grad(points):
+        return _GroupPointFn.apply(points, idx)
+    return _group_point_fwd(points, idx)
+
+
+def three_interpolate(points, idx, weight):
+    """Differentiable front of _three_interpolate_fwd (same contract; see there)."""
+    if _wants_grad(points):
+        return _ThreeInterpolateFn.apply(points, idx, weight)
+    return _three_interpolate_fwd(points, idx, weight)

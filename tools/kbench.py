@@ -75,6 +75,11 @@ def main():
                 us = timeit(lambda: ops.group_point(f, idx), a.iters)
                 by = b * m * ns * (4 + 8 * c)
                 rep("group_point", "b%d m%d ns%d C%d" % (b, m, ns, c), us, by / us / 1e3 / 8000, "%.0f GB/s" % (by / us / 1e3))
+            if want("grad"):
+                go = torch.randn(b, m, ns, c, generator=rng).to(dev)
+                us = timeit(lambda: ops.group_point_grad(f, idx, go), a.iters)
+                by = b * m * ns * (4 + 4 * c) + b * n * c * 4
+                rep("group_point_grad", "b%d n%d m%d ns%d C%d" % (b, n, m, ns, c), us, by / us / 1e3 / 8000, "%.0f GB/s" % (by / us / 1e3))
             cin = c + 3
             W = [(torch.randn(ci, co, generator=rng).mul_(0.1).to(dev), torch.ones(co, device=dev), torch.zeros(co, device=dev))
                  for ci, co in zip([cin] + mlp[:-1], mlp)]
@@ -115,6 +120,11 @@ def main():
             us = timeit(lambda: ops.three_nn_interpolate(x1, x2, p2), a.iters)
             by = b * (12 * n1 + 12 * m2) + b * n1 * 16 * c
             rep("three_nn_interpolate", "b%d n%d m%d C%d" % (b, n1, m2, c), us, by / us / 1e3 / 8000, "%.0f GB/s" % (by / us / 1e3))
+        if want("grad"):
+            go = torch.randn(b, n1, c, generator=rng).to(dev)
+            us = timeit(lambda: ops.three_interpolate_grad(p2, i3, w, go), a.iters)
+            by = b * n1 * (24 + 12 * c) + b * m2 * c * 4
+            rep("three_interpolate_grad", "b%d n%d m%d C%d" % (b, n1, m2, c), us, by / us / 1e3 / 8000, "%.0f GB/s" % (by / us / 1e3))
         c1 = levels[k][1].shape[2] + (3 if k == 0 else 0)
         cin = c + c1
         if want("mlp"):

@@ -11,8 +11,11 @@ matrix cores, followed by the rotated BEV NMS of each scene's 2048 proposals (to
 IoU 0.8: the reference's val/test setting) and -- for N>1 -- ONE all-gather of the
 per-scene detection records.  One "step" = one such batch per rank (weak scaling: every
 rank processes its own 16 scenes per step).  Inputs are resident in HBM before the timed
-region.  Steps are issued round-robin on a few HIP streams so that the strictly serial
-farthest-point-sampling chain of one batch overlaps the matrix work of its neighbours.
+region.  Each step is one HIP-graph replay; steps alternate over two streams, and inside a
+step the strictly serial, 16-CU farthest-point-sampling chain of the NEXT batch of that
+stream runs beside the full-chip feature phase of the current batch (software pipelining
+by one batch: every step still executes exactly one FPS chain and one feature phase, see
+pipelined_step; --no-pipeline samples inside the batch's own step).
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant roofline-bound
 kernel, durations measured with HIP events inside the timed region), `kernels` (every
@@ -59,12 +62,31 @@ def make_inputs(rank, device, batch):
     return pcs, prop
 
 
-def step(pcs, prop, store, precision, geo=None):
+def step(pcs, prop, store, precision, geo=None, centroids=None):
     """SA+FP stack on the batch, per-scene rotated NMS of its proposals, detection records."""
-    feats, _ = stacks.rpn_sa_fp_stack(pcs, params=store, precision=precision, geometry_stream=geo)
+    feats, _ = stacks.rpn_sa_fp_stack(pcs, params=store, precision=precision, geometry_stream=geo,
+                                      centroids=centroids)
     keep, nk = nms_rotate_batched(prop["bev"], prop["scores"], 0.8, pdist.MAX_DET)
     rec = pdist.pack_detections(prop["scene_ids"], prop["boxes3d"], prop["scores"], keep, nk)
     return feats, rec
+
+
+def pipelined_step(pcs_cur, pcs_next, prop, store, precision, cent_cur, cent_next, side):
+    """One step of the software-pipelined schedule: the feature phase of the current batch
+    (grouping, MLPs, interpolation, NMS, records) runs on the current stream with the
+    centroids sampled one step earlier, while the strictly serial FPS chain of the NEXT
+    batch runs on `side` into `cent_next`.  Every step still executes one complete FPS
+    chain and one complete feature phase; only their pairing is shifted by one batch, so the
+    16-CU, latency-bound sampling never gates the full-chip work of its own batch."""
+    cur = torch.cuda.current_stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        xs, _ = stacks.sample_centroid_chain(pcs_next[:, :, 0:3].contiguous(), [lv[0] for lv in stacks.RPN_SA])
+        for dst, x in zip(cent_next, xs):
+            dst.copy_(x)
+    out = step(pcs_cur, prop, store, precision, centroids=cent_cur)
+    cur.wait_stream(side)
+    return out
 
 
 def time_nms(device, n=9000, iters=20):
@@ -140,12 +162,16 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32")
-    ap.add_argument("--streams", type=int, default=3)  # concurrent batches in flight
+    # concurrent batches in flight; each has a companion stream for the next batch's FPS chain,
+    # and 2+2 streams = HIP's 4 hardware queues (measured: 3+3 aliases queues and loses 20 %)
+    ap.add_argument("--streams", type=int, default=2)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--geo-stream", action="store_true",
                     help="run each step's FPS chain on a companion stream (helps only single-batch latency)")
     ap.add_argument("--no-graph", action="store_true", help="issue every step eagerly instead of replaying HIP graphs")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="sample each batch's centroids inside its own step instead of one step ahead")
     args = ap.parse_args()
 
     rank, world, local = pdist.init_from_env("cuda")
@@ -163,7 +189,25 @@ def main():
     # One HIP graph of the whole step per stream (the C ABI allocates nothing and never
     # synchronises, so it captures as is); the all-gather stays outside the graph.
     graphs, outs = [], []
-    if not args.no_graph:
+    pipelined = not (args.no_graph or args.no_pipeline or args.geo_stream)
+    if pipelined:
+        # two graphs per stream (ping-pong over two centroid sets): replay r reads set r%2,
+        # which replay r-1 of the same stream filled, and fills set (r+1)%2
+        sides = [torch.cuda.Stream(device=device) for _ in streams]
+        for st, side in zip(streams, sides):
+            with torch.cuda.stream(st):
+                xs, _ = stacks.sample_centroid_chain(pcs[:, :, 0:3].contiguous(), [lv[0] for lv in stacks.RPN_SA])
+                cents = [[x.clone() for x in xs], [x.clone() for x in xs]]
+                pipelined_step(pcs, pcs, prop, store, precision, cents[0], cents[1], side)   # warm-up
+            torch.cuda.synchronize()
+            pair, opair = [], []
+            for w in (0, 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    o = pipelined_step(pcs, pcs, prop, store, precision, cents[w], cents[1 - w], side)
+                pair.append(g); opair.append(o)
+            graphs.append(pair); outs.append(opair)
+    elif not args.no_graph:
         for st, geo in zip(streams, geos):
             with torch.cuda.stream(st):
                 step(pcs, prop, store, precision, geo)             # lazy init + allocator warm-up
@@ -173,13 +217,20 @@ def main():
                 o = step(pcs, prop, store, precision, geo)
             graphs.append(g); outs.append(o)
 
+    replays = [0] * len(streams)
+
     def run_steps(k, timer=None):
         prev = ops.set_timer(timer)
         try:
             for i in range(k):
                 j = i % len(streams)
                 with torch.cuda.stream(streams[j]):
-                    if graphs and timer is None:
+                    if graphs and timer is None and pipelined:
+                        w = replays[j] & 1
+                        replays[j] += 1
+                        graphs[j][w].replay()
+                        rec = outs[j][w][1]
+                    elif graphs and timer is None:
                         graphs[j].replay()
                         rec = outs[j][1]
                     else:
@@ -290,7 +341,7 @@ def main():
                                    (args.batch, NPTS, NPROP, " + RCCL all-gather of detections" if world > 1 else ""),
                        "batch_per_gpu": args.batch, "points": NPTS, "streams": len(streams),
                        "hip_graph": bool(graphs), "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3),
-                       "geometry_streams": bool(args.geo_stream),
+                       "geometry_streams": bool(args.geo_stream), "fps_one_step_ahead": bool(pipelined),
                        "kernel_timing": "HIP events around every launch in an eager, single-stream instrumented "
                                         "pass of the same steps after the timed region",
                        "parallelism": "scene-sharded x%d" % world},

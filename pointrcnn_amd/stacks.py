@@ -48,7 +48,7 @@ def sample_centroid_chain(l0_xyz, npoints, stream=None):
 
 
 def rpn_sa_fp_stack(point_cloud, params=None, precision=None, is_training=False, bn_decay=None,
-                    geometry_stream=None):
+                    geometry_stream=None, centroids=None):
     """point_cloud (B,N,4) -> per-point features (B,N,128); also returns the level xyz/feature lists.
     With `geometry_stream` the FPS chain of all four levels runs on that stream, overlapped
     with the grouping / MLP work of the main stream (same results)."""
@@ -56,10 +56,14 @@ def rpn_sa_fp_stack(point_cloud, params=None, precision=None, is_training=False,
     l0_points = point_cloud[:, :, 3:].contiguous() if point_cloud.shape[2] > 3 else None
     xyzs, feats = [l0_xyz], [l0_points]
     pre, evs = (None, None)
-    if geometry_stream is not None:
+    if centroids is not None:
+        # the four levels' new_xyz were sampled beforehand (sample_centroid_chain on the same
+        # cloud, e.g. while the previous batch was in its feature phase): same results
+        pre, evs = list(centroids), None
+    elif geometry_stream is not None:
         pre, evs = sample_centroid_chain(l0_xyz, [lv[0] for lv in RPN_SA], geometry_stream)
     for li, (npoint, radii, nsamples, mlps) in enumerate(RPN_SA):
-        if pre is not None:
+        if evs is not None:
             torch.cuda.current_stream().wait_event(evs[li])
         x, f = pointnet_sa_module_msg(xyzs[-1], feats[-1], npoint, radii, nsamples, mlps, is_training,
                                       bn_decay, scope='layer%d' % (li + 1), bn=True, params=params,

@@ -201,6 +201,23 @@ int prcnn_sa_group_mlp3_pool(int b, int n, int m, int nsample, int c, const floa
 int prcnn_max_pool(int64_t groups, int nsample, int c, const float *x, int64_t ldx, float *out,
                    int64_t ldo, prcnn_stream_t stream);
 
+/* ---- spatially culled three_nn (additive; same results as prcnn_three_nn) -----------------
+ * For large n*m: queries and known points are bucketed into a Morton-ordered grid, known
+ * points are cut into boxed tiles of 64, and each wave of 64 neighbouring queries visits
+ * tiles nearest-first until the nearest unvisited tile is farther than its worst
+ * third-best distance.  The bound uses the same unfused fp32 operations as the distance
+ * (monotone under rounding), and insertion orders (distance, index) pairs, so dist/idx
+ * are bit-identical to threenn_cpu (tf_interpolate.cpp:60-103) for every input.
+ * workspace: *_workspace_bytes(), 256-byte aligned, contents irrelevant on entry. */
+size_t prcnn_three_nn_sorted_workspace_bytes(int b, int n, int m);
+int prcnn_three_nn_sorted(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist,
+                          int *idx, void *workspace, size_t workspace_bytes, prcnn_stream_t stream);
+/* prcnn_three_nn_interpolate with the culled search (dist / idx may be NULL). */
+int prcnn_three_nn_interpolate_sorted(int b, int n, int m, int c, const float *xyz1,
+                                      const float *xyz2, const float *points2, float *out,
+                                      int64_t ldo, float *dist, int *idx, void *workspace,
+                                      size_t workspace_bytes, prcnn_stream_t stream);
+
 /* ---- backward ops ------------------------------------------------
  * All three are ordered segmented reductions: every output element is summed in exactly
  * the order of the reference's serial CPU loops, so results are deterministic and equal

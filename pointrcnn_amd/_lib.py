@@ -43,6 +43,9 @@ SIGNATURES = {
     "prcnn_sa_group_mlp3_pool": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i] + [_vp] * 9 +
                                  [_vp, _i64, _vp]),
     "prcnn_max_pool": (_i, [_i64, _i, _i, _vp, _i64, _vp, _i64, _vp]),
+    "prcnn_three_nn_sorted_workspace_bytes": (_sz, [_i, _i, _i]),
+    "prcnn_three_nn_sorted": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "prcnn_three_nn_interpolate_sorted": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "prcnn_gather_point_grad_workspace_bytes": (_sz, [_i, _i, _i]),
     "prcnn_gather_point_grad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "prcnn_group_point_grad_workspace_bytes": (_sz, [_i, _i, _i, _i]),

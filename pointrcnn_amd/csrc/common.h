@@ -62,4 +62,33 @@ __device__ __forceinline__ int wave_max_i32(int v)
 __device__ __forceinline__ int f2i(float f) { return __builtin_bit_cast(int, f); }
 __device__ __forceinline__ float i2f(int i) { return __builtin_bit_cast(float, i); }
 
+// ---- three smallest (distance, index) pairs, branch-free -----------------------------------
+// threenn_cpu (tf_interpolate.cpp:74-89) inserts with strict '<' while the index increases,
+// i.e. it keeps the three smallest pairs under the lexicographic order (distance, index).
+// A pair is held as one 64-bit key  (bits(distance) << 32) | index : distances are >= +0, so
+// the unsigned order of the keys IS that lexicographic order (NaN sorts above +inf and never
+// enters).  Insertion is three 64-bit compares and five selects with no divergence, so a
+// wave pays the same whether one lane or all of them take a candidate, in any visiting order.
+struct Top3K {
+    unsigned long long k1, k2, k3;
+    float d3;                        // distance half of k3 (screening value)
+};
+__device__ __forceinline__ Top3K top3k_init()
+{
+    const unsigned long long e = (unsigned long long)0x7f800000u << 32;      // (+inf, 0)
+    Top3K t = {e, e, e, i2f(0x7f800000)};
+    return t;
+}
+__device__ __forceinline__ void top3k_insert(Top3K &t, float d, int i)
+{
+    const unsigned long long c = ((unsigned long long)(unsigned)f2i(d) << 32) | (unsigned)i;
+    const bool l1 = c < t.k1, l2 = c < t.k2, l3 = c < t.k3;
+    t.k3 = l2 ? t.k2 : (l3 ? c : t.k3);
+    t.k2 = l1 ? t.k1 : (l2 ? c : t.k2);
+    t.k1 = l1 ? c : t.k1;
+    t.d3 = i2f((int)(t.k3 >> 32));
+}
+__device__ __forceinline__ float top3k_dist(unsigned long long k) { return i2f((int)(k >> 32)); }
+__device__ __forceinline__ int top3k_index(unsigned long long k) { return (int)(unsigned)k; }
+
 }  // namespace prcnn

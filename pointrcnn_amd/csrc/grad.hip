@@ -18,31 +18,30 @@
 // read once, each output row written once (rows nobody points at get their zeros from
 // step 5: no memset of the output), and no float atomic touches L2.
 #include "common.h"
+#include "csr.h"
 
 namespace prcnn {
 
 constexpr int GR_THREADS = 256;
 constexpr int SORT_LDS_MAX = 1024;      // segment lengths up to this are ranked from LDS
 
-struct ScatterWs {
-    int *off;        // (b, nd+1): after the scan, off[bi][k] = first slot of row k
-    int *cursor;     // (b, nd)
-    int *list;       // (b, E): entry numbers grouped by destination row
-};
+typedef CsrWs ScatterWs;
 
-static size_t scatter_ws_ints(long long b, long long nd, long long E)
+size_t csr_ws_ints(long long b, long long nd, long long E)
 {
     return (size_t)(b * (nd + 1) + b * nd + b * E);
 }
+static size_t scatter_ws_ints(long long b, long long nd, long long E) { return csr_ws_ints(b, nd, E); }
 
-static ScatterWs carve(void *ws, long long b, long long nd, long long E)
+CsrWs csr_carve(void *ws, long long b, long long nd, long long E)
 {
-    ScatterWs w;
+    CsrWs w;
     w.off = reinterpret_cast<int *>(ws);
     w.cursor = w.off + b * (nd + 1);
     w.list = w.cursor + b * nd;
     return w;
 }
+static ScatterWs carve(void *ws, long long b, long long nd, long long E) { return csr_carve(ws, b, nd, E); }
 
 __global__ void scatter_count_kernel(long long total, long long E, int nd, const int *__restrict__ keys,
                                      int *__restrict__ off)
@@ -220,6 +219,32 @@ static int grid_for(long long items, int per_block, int cap)
     return (int)g;
 }
 
+// keys (b, E) -> w.off (b, nd+1) row starts, w.list (b, E) entries grouped by row
+// (ascending inside each row when sort_rows).  Keys outside [0, nd) are left out.
+int csr_build(int b, int nd, long long E, const int *keys, CsrWs w, bool sort_rows, hipStream_t st)
+{
+    const long long rows = (long long)b * nd;
+    if (hipMemsetAsync(w.off, 0, (size_t)b * (nd + 1) * sizeof(int), st) != hipSuccess) {
+        prcnn_note_hip_error((int)hipGetLastError());
+        return PRCNN_HIP_ERROR;
+    }
+    const long long total = (long long)b * E;
+    if (total > 0) {
+        hipLaunchKernelGGL(scatter_count_kernel, dim3(grid_for(total, GR_THREADS, 4096)), dim3(GR_THREADS), 0, st,
+                           total, E, nd, keys, w.off);
+    }
+    hipLaunchKernelGGL(scatter_scan_kernel, dim3(b), dim3(1024), 0, st, nd, w.off, w.cursor);
+    if (total > 0) {
+        hipLaunchKernelGGL(scatter_fill_kernel, dim3(grid_for(total, GR_THREADS, 4096)), dim3(GR_THREADS), 0, st,
+                           total, E, nd, keys, w.cursor, w.list);
+        if (sort_rows)
+            hipLaunchKernelGGL(scatter_sort_kernel, dim3(grid_for(rows, GR_THREADS / 64, 8192)), dim3(GR_THREADS), 0,
+                               st, rows, E, nd, keys, w.off, w.list);
+    }
+    PRCNN_LAUNCH_CHECK();
+    return PRCNN_OK;
+}
+
 // keys: (b, E) destination rows; src: (b, E/DIV, c); weight: (b, E) or null; dst: (b, nd, c)
 template <int DIV, bool WEIGHTED>
 static int scatter_add_ordered(int b, int nd, long long E, int c, const int *keys, const float *src,
@@ -234,22 +259,8 @@ static int scatter_add_ordered(int b, int nd, long long E, int c, const int *key
     if (!ws || ws_bytes < need) return PRCNN_WORKSPACE;
     if (((uintptr_t)ws & 3) != 0) return PRCNN_BAD_ARG;
     ScatterWs w = carve(ws, b, nd, E);
-    if (hipMemsetAsync(w.off, 0, (size_t)b * (nd + 1) * sizeof(int), st) != hipSuccess) {
-        prcnn_note_hip_error((int)hipGetLastError());
-        return PRCNN_HIP_ERROR;
-    }
-    const long long total = (long long)b * E;
-    if (total > 0) {
-        hipLaunchKernelGGL(scatter_count_kernel, dim3(grid_for(total, GR_THREADS, 4096)), dim3(GR_THREADS), 0, st,
-                           total, E, nd, keys, w.off);
-    }
-    hipLaunchKernelGGL(scatter_scan_kernel, dim3(b), dim3(1024), 0, st, nd, w.off, w.cursor);
-    if (total > 0) {
-        hipLaunchKernelGGL(scatter_fill_kernel, dim3(grid_for(total, GR_THREADS, 4096)), dim3(GR_THREADS), 0, st,
-                           total, E, nd, keys, w.cursor, w.list);
-        hipLaunchKernelGGL(scatter_sort_kernel, dim3(grid_for(rows, GR_THREADS / 64, 8192)), dim3(GR_THREADS), 0,
-                           st, rows, E, nd, keys, w.off, w.list);
-    }
+    const int rc = csr_build(b, nd, E, keys, w, true, st);
+    if (rc != PRCNN_OK) return rc;
     const bool v4 = c % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
     const int lanes = v4 ? c / 4 : c;
     int T = 1;

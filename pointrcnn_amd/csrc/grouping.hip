@@ -40,7 +40,9 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(int n, int m, co
                                                                 const float *__restrict__ xyz1,
                                                                 const float *__restrict__ xyz2)
 {
-    __shared__ float sx[BQ_TILE], sy[BQ_TILE], sz[BQ_TILE];
+    // the tile is a straight copy of the cloud (x,y,z interleaved): a lane reads its point at
+    // word 3*lane + {0,1,2}; stride 3 is coprime with the 64 banks, so the reads are conflict-free
+    __shared__ __attribute__((aligned(16))) float sp[BQ_TILE * 3];
     const int tid = threadIdx.x, lane = tid & 63;
     // wave-uniform by construction; readfirstlane tells the compiler, so that the per-centroid
     // counters, flags and centroid coordinates live in SGPRs and all control flow is scalar
@@ -66,58 +68,87 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(int n, int m, co
         }
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
+    // thr_open[c]: largest threshold among the scales of centroid c that still take points
+    // (-inf once all are full), so ONE compare per centroid screens a 64-point step and the
+    // per-scale bookkeeping below only runs for steps that contain a hit.
+    float thr_open[BQ_CPW];
+    auto refresh = [&](int c) {
+        float t = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (cnt[c][s] < sc.nsample[s]) t = fmaxf(t, sc.thr2[s]);
+        thr_open[c] = t;
+    };
+#pragma unroll
+    for (int c = 0; c < BQ_CPW; ++c) refresh(c);
 
     const float nanv = __builtin_nanf("");
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     for (int base = 0; base < n; base += BQ_TILE) {
         const int tn = min(BQ_TILE, n - base);
         const int tn64 = (tn + 63) & ~63;
         __syncthreads();
-        for (int e = tid; e < tn * 3; e += BQ_THREADS) {
-            const float v = pts[(size_t)base * 3 + e];
-            const int p = e / 3, c = e - p * 3;
-            (c == 0 ? sx : c == 1 ? sy : sz)[p] = v;
+        {
+            const float *src = pts + (size_t)base * 3;
+            const int nf = tn * 3;
+            if ((((uintptr_t)src) & 15) == 0) {
+                const int nv = nf >> 2;
+                for (int e = tid; e < nv; e += BQ_THREADS)
+                    reinterpret_cast<float4 *>(sp)[e] = reinterpret_cast<const float4 *>(src)[e];
+                for (int e = (nv << 2) + tid; e < nf; e += BQ_THREADS) sp[e] = src[e];
+            } else {
+                for (int e = tid; e < nf; e += BQ_THREADS) sp[e] = src[e];
+            }
         }
         // tail of the last 64-point chunk: NaN coordinates never pass  d2 < thr2
-        for (int p = tn + tid; p < tn64; p += BQ_THREADS) { sx[p] = nanv; sy[p] = nanv; sz[p] = nanv; }
+        for (int e = tn * 3 + tid; e < tn64 * 3; e += BQ_THREADS) sp[e] = nanv;
         __syncthreads();
-        for (int p0 = 0; p0 < tn64; p0 += 64) {
-            bool any_active = false;                 // wave-uniform
-            const float x1 = sx[p0 + lane], y1 = sy[p0 + lane], z1 = sz[p0 + lane];
+        bool open = false;                           // wave-uniform: some centroid still takes points
+#pragma unroll
+        for (int c = 0; c < BQ_CPW; ++c) open = open || thr_open[c] > -INFINITY;
+        for (int p0 = 0; p0 < tn64 && open; p0 += 64) {
+            const float *pp = sp + (p0 + lane) * 3;
+            const float x1 = pp[0], y1 = pp[1], z1 = pp[2];
             const int k = base + p0 + lane;
+            // two centroids per packed-fp32 operation (v_pk_add/mul_f32: each component is the
+            // same IEEE operation as the scalar form, so decisions are bit-identical)
+            const f32x2 px = {x1, x1}, py = {y1, y1}, pz = {z1, z1};
+            float d2[BQ_CPW];
+            unsigned long long any = 0;
+#pragma unroll
+            for (int c0 = 0; c0 < BQ_CPW; c0 += 2) {
+                const f32x2 ccx = {cx[c0], cx[c0 + 1]}, ccy = {cy[c0], cy[c0 + 1]}, ccz = {cz[c0], cz[c0 + 1]};
+                const f32x2 dx = ccx - px, dy = ccy - py, dz = ccz - pz;
+                const f32x2 d2p = dx * dx + dy * dy + dz * dz;
+                d2[c0] = d2p[0]; d2[c0 + 1] = d2p[1];
+                any |= __builtin_amdgcn_ballot_w64(d2p[0] < thr_open[c0]);
+                any |= __builtin_amdgcn_ballot_w64(d2p[1] < thr_open[c0 + 1]);
+            }
+            if (any == 0) continue;
 #pragma unroll
             for (int c = 0; c < BQ_CPW; ++c) {
-                bool active = false;
 #pragma unroll
-                for (int s = 0; s < NS; ++s) active = active || cnt[c][s] < sc.nsample[s];
-                if (active) {
-                    const float dx = cx[c] - x1, dy = cy[c] - y1, dz = cz[c] - z1;
-                    const float d2 = dx * dx + dy * dy + dz * dz;
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) {
-                        if (cnt[c][s] < sc.nsample[s]) {
-                            const bool hit = d2 < sc.thr2[s];
-                            const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-                            if (mask) {
-                                if (cnt[c][s] == 0) first[c][s] = base + p0 + __builtin_ctzll(mask);
-                                const int slot = cnt[c][s] + __builtin_popcountll(mask & lt);
-                                if (hit && slot < sc.nsample[s])
-                                    sc.idx[s][((size_t)bi * m + j0 + c) * sc.nsample[s] + slot] = k;
-                                cnt[c][s] += __builtin_popcountll(mask);
-                            }
+                for (int s = 0; s < NS; ++s) {
+                    if (cnt[c][s] < sc.nsample[s]) {
+                        const bool hit = d2[c] < sc.thr2[s];
+                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                        if (mask) {
+                            if (cnt[c][s] == 0) first[c][s] = base + p0 + __builtin_ctzll(mask);
+                            const int slot = cnt[c][s] + __builtin_popcountll(mask & lt);
+                            if (hit && slot < sc.nsample[s])
+                                sc.idx[s][((size_t)bi * m + j0 + c) * sc.nsample[s] + slot] = k;
+                            cnt[c][s] += __builtin_popcountll(mask);
                         }
                     }
-                    any_active = true;
                 }
+                refresh(c);
             }
-            if (!any_active) break;
+            open = false;
+#pragma unroll
+            for (int c = 0; c < BQ_CPW; ++c) open = open || thr_open[c] > -INFINITY;
         }
         // the whole workgroup leaves once every centroid of every wave is full
-        bool done = true;
-#pragma unroll
-        for (int c = 0; c < BQ_CPW; ++c)
-#pragma unroll
-            for (int s = 0; s < NS; ++s) done = done && cnt[c][s] >= sc.nsample[s];
-        if (__syncthreads_and(done)) break;
+        if (__syncthreads_and(!open)) break;
     }
     // pad rows that found fewer than nsample points with the first hit
     // (tf_grouping_g.cu:26-29); rows without any hit are zero-filled.

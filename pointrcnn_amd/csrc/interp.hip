@@ -21,67 +21,64 @@ namespace prcnn {
 constexpr int NN_THREADS = 256;
 constexpr int NN_TILE = 2048;
 
-struct Top3 {
-    float d1, d2, d3;
-    int i1, i2, i3;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Known points sit in LDS as PAIRS: xy[k/2] = (x_k, x_k+1, y_k, y_k+1), zz[k/2] = (z_k, z_k+1),
+// so that two candidates go through every v_pk_add/mul_f32 (each component is the same IEEE
+// operation as the scalar form: bit-identical distances, tf_interpolate.cpp:73 order, unfused).
+struct PairTile {
+    float4 xy[NN_TILE / 2];
+    f32x2 zz[NN_TILE / 2];
 };
 
-__device__ __forceinline__ void top3_insert(Top3 &t, float d, int kk)
+__device__ __forceinline__ f32x2 sqdist2(const float4 xy, const f32x2 zz, f32x2 qx, f32x2 qy, f32x2 qz)
 {
-    if (d < t.d3) {                                   // tf_interpolate.cpp:74-89
-        if (d < t.d1) {
-            t.d3 = t.d2; t.i3 = t.i2;
-            t.d2 = t.d1; t.i2 = t.i1;
-            t.d1 = d; t.i1 = kk;
-        } else if (d < t.d2) {
-            t.d3 = t.d2; t.i3 = t.i2;
-            t.d2 = d; t.i2 = kk;
-        } else {
-            t.d3 = d; t.i3 = kk;
-        }
-    }
-}
-
-__device__ __forceinline__ float sqdist(const float4 p, float x1, float y1, float z1)
-{
-    const float dx = p.x - x1, dy = p.y - y1, dz = p.z - z1;
-    return dx * dx + dy * dy + dz * dz;               // tf_interpolate.cpp:73, unfused
+    const f32x2 px = {xy.x, xy.y}, py = {xy.z, xy.w};
+    const f32x2 dx = px - qx, dy = py - qy, dz = zz - qz;
+    return dx * dx + dy * dy + dz * dz;
 }
 
 // The tile is padded to a multiple of 4 with NaN points (never smaller than anything).
-// Four candidates per step; the insertion chain only runs when one of them can enter the
-// top 3, and then visits them in index order, so ties resolve exactly as in the reference.
-__device__ __forceinline__ void top3_scan(Top3 &t, float x1, float y1, float z1,
-                                          const float4 *__restrict__ tile, int tn, int base)
+// Four candidates per step behind ONE wave-uniform screen (strict '<': candidates arrive in
+// index order, so an equal distance never displaces an earlier index); a candidate is inserted (by every
+// lane at once, branch-free, see Top3K in common.h) only if some lane can take it.  With
+// random point order a wave of 64 queries still takes ~800 of 4096 candidates, so the cost of
+// the insertion path, not the distance arithmetic, is what this loop is shaped around.
+__device__ __forceinline__ void top3_scan(Top3K &t, float x1, float y1, float z1,
+                                          const PairTile &tile, int tn, int base)
 {
     const int tn4 = (tn + 3) & ~3;
+    const f32x2 qx = {x1, x1}, qy = {y1, y1}, qz = {z1, z1};
     for (int k = 0; k < tn4; k += 4) {
-        const float d0 = sqdist(tile[k], x1, y1, z1);
-        const float d1 = sqdist(tile[k + 1], x1, y1, z1);
-        const float d2 = sqdist(tile[k + 2], x1, y1, z1);
-        const float d3 = sqdist(tile[k + 3], x1, y1, z1);
-        const float mn = fminf(fminf(d0, d1), fminf(d2, d3));
-        if (mn < t.d3) {
-            top3_insert(t, d0, base + k);
-            top3_insert(t, d1, base + k + 1);
-            top3_insert(t, d2, base + k + 2);
-            top3_insert(t, d3, base + k + 3);
+        const f32x2 da = sqdist2(tile.xy[k >> 1], tile.zz[k >> 1], qx, qy, qz);
+        const f32x2 db = sqdist2(tile.xy[(k >> 1) + 1], tile.zz[(k >> 1) + 1], qx, qy, qz);
+        const float mn = fminf(fminf(da[0], da[1]), fminf(db[0], db[1]));
+        if (__builtin_amdgcn_ballot_w64(mn < t.d3)) {
+            if (__builtin_amdgcn_ballot_w64(da[0] < t.d3)) top3k_insert(t, da[0], base + k);
+            if (__builtin_amdgcn_ballot_w64(da[1] < t.d3)) top3k_insert(t, da[1], base + k + 1);
+            if (__builtin_amdgcn_ballot_w64(db[0] < t.d3)) top3k_insert(t, db[0], base + k + 2);
+            if (__builtin_amdgcn_ballot_w64(db[1] < t.d3)) top3k_insert(t, db[1], base + k + 3);
         }
     }
 }
 
-__device__ __forceinline__ void stage_tile(float4 *tile, const float *__restrict__ known, int base,
+__device__ __forceinline__ void stage_tile(PairTile &tile, const float *__restrict__ known, int base,
                                            int tn, int tid, int nthreads)
 {
     const int tn4 = (tn + 3) & ~3;
     const float nan = __builtin_nanf("");
+    float *xy = reinterpret_cast<float *>(tile.xy);
+    float *zz = reinterpret_cast<float *>(tile.zz);
     for (int k = tid; k < tn4; k += nthreads) {
+        float x = nan, y = nan, z = nan;
         if (k < tn) {
             const float *p = known + (size_t)(base + k) * 3;
-            tile[k] = make_float4(p[0], p[1], p[2], 0.f);
-        } else {
-            tile[k] = make_float4(nan, nan, nan, 0.f);
+            x = p[0]; y = p[1]; z = p[2];
         }
+        const int h = k & 1, pr = k >> 1;
+        xy[pr * 4 + h] = x;
+        xy[pr * 4 + 2 + h] = y;
+        zz[pr * 2 + h] = z;
     }
 }
 
@@ -91,14 +88,14 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(int n, int m,
                                                               float *__restrict__ dist,
                                                               int *__restrict__ idx)
 {
-    __shared__ float4 tile[NN_TILE];
+    __shared__ PairTile tile;
     const int bi = blockIdx.y;
     const int j = blockIdx.x * NN_THREADS + threadIdx.x;
     const bool ok = j < n;
     const float *q = xyz1 + ((size_t)bi * n + (ok ? j : 0)) * 3;
     const float x1 = q[0], y1 = q[1], z1 = q[2];
     const float *known = xyz2 + (size_t)bi * m * 3;
-    Top3 t = {INFINITY, INFINITY, INFINITY, 0, 0, 0};
+    Top3K t = top3k_init();
     for (int base = 0; base < m; base += NN_TILE) {
         const int tn = min(NN_TILE, m - base);
         __syncthreads();
@@ -108,8 +105,8 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(int n, int m,
     }
     if (ok) {
         const size_t o = ((size_t)bi * n + j) * 3;
-        dist[o + 0] = t.d1; dist[o + 1] = t.d2; dist[o + 2] = t.d3;
-        idx[o + 0] = t.i1; idx[o + 1] = t.i2; idx[o + 2] = t.i3;
+        dist[o + 0] = top3k_dist(t.k1); dist[o + 1] = top3k_dist(t.k2); dist[o + 2] = top3k_dist(t.k3);
+        idx[o + 0] = top3k_index(t.k1); idx[o + 1] = top3k_index(t.k2); idx[o + 2] = top3k_index(t.k3);
     }
 }
 
@@ -168,7 +165,7 @@ __global__ __launch_bounds__(FU_THREADS) void three_nn_interpolate_kernel(
     float *__restrict__ dist, int *__restrict__ idx)
 {
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
-    __shared__ float4 tile[NN_TILE];
+    __shared__ PairTile tile;
     __shared__ int s_i[FU_THREADS * 3];
     __shared__ float s_w[FU_THREADS * 3];
     const int tid = threadIdx.x;
@@ -179,7 +176,7 @@ __global__ __launch_bounds__(FU_THREADS) void three_nn_interpolate_kernel(
     const float *q = xyz1 + ((size_t)bi * n + (ok ? j : 0)) * 3;
     const float x1 = q[0], y1 = q[1], z1 = q[2];
     const float *known = xyz2 + (size_t)bi * m * 3;
-    Top3 t = {INFINITY, INFINITY, INFINITY, 0, 0, 0};
+    Top3K t = top3k_init();
     for (int base = 0; base < m; base += NN_TILE) {
         const int tn = min(NN_TILE, m - base);
         __syncthreads();
@@ -188,13 +185,15 @@ __global__ __launch_bounds__(FU_THREADS) void three_nn_interpolate_kernel(
         top3_scan(t, x1, y1, z1, tile, tn, base);
     }
     float w0, w1, w2;
-    fp_weights3(t.d1, t.d2, t.d3, w0, w1, w2);
-    s_i[tid * 3] = t.i1; s_i[tid * 3 + 1] = t.i2; s_i[tid * 3 + 2] = t.i3;
+    const float e1 = top3k_dist(t.k1), e2 = top3k_dist(t.k2), e3 = top3k_dist(t.k3);
+    const int i1 = top3k_index(t.k1), i2 = top3k_index(t.k2), i3 = top3k_index(t.k3);
+    fp_weights3(e1, e2, e3, w0, w1, w2);
+    s_i[tid * 3] = i1; s_i[tid * 3 + 1] = i2; s_i[tid * 3 + 2] = i3;
     s_w[tid * 3] = w0; s_w[tid * 3 + 1] = w1; s_w[tid * 3 + 2] = w2;
     if (ok) {
         const size_t o = ((size_t)bi * n + j) * 3;
-        if (dist) { dist[o] = t.d1; dist[o + 1] = t.d2; dist[o + 2] = t.d3; }
-        if (idx) { idx[o] = t.i1; idx[o + 1] = t.i2; idx[o + 2] = t.i3; }
+        if (dist) { dist[o] = e1; dist[o + 1] = e2; dist[o + 2] = e3; }
+        if (idx) { idx[o] = i1; idx[o + 1] = i2; idx[o + 2] = i3; }
     }
     __syncthreads();
     const int rows = min(FU_THREADS, n - j0);

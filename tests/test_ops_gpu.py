@@ -230,3 +230,32 @@ def test_query_ball_msg_equals_per_radius_calls(cuda):
         for (idx, cnt), r, ns in zip(res, radii, nss):
             oi, oc = O.query_ball_point(r, ns, pts, cen)
             assert np.array_equal(npy(idx), oi) and np.array_equal(npy(cnt), oc)
+
+
+def test_three_nn_culled_search_is_bit_identical(cuda):
+    """prcnn_three_nn_sorted / prcnn_three_nn_interpolate_sorted (additive entry points):
+    same dist / idx / interpolated values as the brute-force kernels, including heavy ties,
+    identical known points, m < 3 and identical queries."""
+    g = torch.Generator().manual_seed(0)
+    pc = torch.as_tensor(S.kitti_batch(0, 2)).to(cuda)
+    xyz = pc[:, :, :3].contiguous()
+    x2 = ops.gather_point(xyz, ops.farthest_point_sample(1024, xyz))
+    lattice_q = torch.randint(0, 4, (2, 3000, 3), generator=g).float().to(cuda)
+    lattice_k = torch.randint(0, 4, (2, 500, 3), generator=g).float().to(cuda)
+    k2 = torch.randn(2, 300, 3, generator=g).to(cuda)
+    cases = [(xyz, x2), (torch.randn(3, 5000, 3, generator=g).to(cuda), torch.randn(3, 777, 3, generator=g).to(cuda)),
+             (lattice_q, lattice_k), (lattice_q, k2[:, :1].contiguous().repeat(1, 300, 1)),
+             (lattice_q, k2[:, :2].contiguous()), (torch.zeros(1, 100, 3, device=cuda), k2[:1])]
+    saved = (ops.NN_SORTED_MIN_TESTS, ops.NN_SORTED_MIN_M)
+    try:
+        for a, k in cases:
+            ops.NN_SORTED_MIN_TESTS = None
+            d0, i0 = ops.three_nn(a, k)
+            feats = torch.randn(k.shape[0], k.shape[1], 20, generator=g).to(cuda)
+            o0 = ops.three_nn_interpolate(a, k, feats)
+            ops.NN_SORTED_MIN_TESTS, ops.NN_SORTED_MIN_M = 0, 1
+            d1, i1 = ops.three_nn(a, k)
+            o1 = ops.three_nn_interpolate(a, k, feats)
+            assert torch.equal(d0, d1) and torch.equal(i0, i1) and torch.equal(o0, o1)
+    finally:
+        ops.NN_SORTED_MIN_TESTS, ops.NN_SORTED_MIN_M = saved

@@ -4,7 +4,7 @@
 // (reference: threenn_cpu, models/tf_ops/3d_interpolation/tf_interpolate.cpp:60-103), but
 // the b*n*m brute-force tests are cut by an order of magnitude:
 //   1. per cloud, queries and known points are bucketed into a uniform Morton-ordered grid
-//      over their joint bounding box (integer-atomic counting sort, csr.h);
+//      over their joint bounding box (one workgroup per set: counting sort in LDS);
 //   2. the sorted known points are cut into tiles of 64 with a bounding box each;
 //   3. a wave owns 64 consecutive sorted queries (a compact box); it visits known tiles in
 //      order of increasing box-to-box distance and stops when the nearest unvisited tile is
@@ -16,25 +16,32 @@
 // index order equals "three smallest by (distance, index)"; since tiles are not visited
 // in index order, insertion here compares (distance, index) pairs lexicographically.
 #include "common.h"
-#include "csr.h"
 
 namespace prcnn {
 
 constexpr int NS_THREADS = 256;
-constexpr int NS_CHUNK = 2048;            // known points per LDS pass
-constexpr int NS_BITS = 5;                // grid cells per axis = 32 (uniform cell size)
-constexpr int NS_CELLS = 1 << (3 * NS_BITS);
+constexpr int NS_KEY_BITS = 15;           // grid cells per cloud = 32768 (128 KB LDS histogram)
+constexpr int NS_CELLS = 1 << NS_KEY_BITS;
 
-// ---- 1. joint bounding box per cloud -----------------------------------------------------
-__global__ __launch_bounds__(1024) void ns_bbox_kernel(int n, int m, const float *__restrict__ xyz1,
+// ---- 1+2. per-cloud counting sort of one point set by grid cell, entirely in LDS -----------
+// grid (2, b): blockIdx.x = 0 sorts the queries, 1 the known points.  Both workgroups derive
+// the same grid from the joint bounding box: a uniform cell size, doubled until the cell
+// coordinates of the three axes fit NS_KEY_BITS bits together (a flat KITTI scene gets
+// e.g. 7+2+6 bits, a cubic cloud 5+5+5), interleaved low bits first (Morton-like order).
+// The order inside a cell is whatever the LDS atomics produce: results do not depend on it.
+__global__ __launch_bounds__(1024) void ns_sort_kernel(int n, int m, const float *__restrict__ xyz1,
                                                        const float *__restrict__ xyz2,
-                                                       float *__restrict__ bbox)
+                                                       int *__restrict__ list_q, int *__restrict__ list_k)
 {
+    __shared__ int hist[NS_CELLS];
     __shared__ float red[16][6];
-    const int bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    __shared__ float sbox[4];
+    __shared__ int sbits[3];
+    __shared__ int wsum[16];
+    const int bi = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *a = xyz1 + (size_t)bi * n * 3;
     const float *k = xyz2 + (size_t)bi * m * 3;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = tid; i < n + m; i += 1024) {
         const float *p = i < n ? a + (size_t)i * 3 : k + (size_t)(i - n) * 3;
 #pragma unroll
@@ -53,54 +60,88 @@ __global__ __launch_bounds__(1024) void ns_bbox_kernel(int n, int m, const float
         }
     if (lane == 0)
         for (int d = 0; d < 3; ++d) { red[wave][d] = lo[d]; red[wave][3 + d] = hi[d]; }
-    __syncthreads();
-    if (tid < 6) {
-        float v = red[0][tid];
-        for (int w = 1; w < 16; ++w) v = tid < 3 ? fminf(v, red[w][tid]) : fmaxf(v, red[w][tid]);
-        bbox[bi * 8 + tid] = v;
-    }
+    for (int c = tid; c < NS_CELLS; c += 1024) hist[c] = 0;
     __syncthreads();
     if (tid == 0) {
-        float ext = 0.f;
-        for (int d = 0; d < 3; ++d) ext = fmaxf(ext, bbox[bi * 8 + 3 + d] - bbox[bi * 8 + d]);
-        // cells per unit length; 0 for a degenerate or non-finite cloud (everything in cell 0)
-        const float inv = (ext > 0.f && ext < INFINITY) ? (float)(1 << NS_BITS) / ext : 0.f;
-        bbox[bi * 8 + 6] = inv;
-    }
-}
-
-__device__ __forceinline__ unsigned spread3(unsigned v)    // 5 bits -> every third bit
-{
-    v &= 0x3ffu;
-    v = (v | (v << 16)) & 0x30000ffu;
-    v = (v | (v << 8)) & 0x300f00fu;
-    v = (v | (v << 4)) & 0x30c30c3u;
-    v = (v | (v << 2)) & 0x9249249u;
-    return v;
-}
-
-// ---- 2. Morton cell of every point -------------------------------------------------------
-__global__ void ns_key_kernel(long long total, int npts, const float *__restrict__ xyz,
-                              const float *__restrict__ bbox, int *__restrict__ keys)
-{
-    for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < total;
-         g += (long long)gridDim.x * blockDim.x) {
-        const long long bi = g / npts;
-        const float *bb = bbox + bi * 8;
-        const float inv = bb[6];
-        unsigned c[3];
-#pragma unroll
+        float blo[3], ext[3], mx = 0.f;
         for (int d = 0; d < 3; ++d) {
-            const float f = (xyz[g * 3 + d] - bb[d]) * inv;
-            int q = f > 0.f ? (int)fminf(f, (float)((1 << NS_BITS) - 1)) : 0;   // NaN -> 0
-            c[d] = (unsigned)q;
+            float l = red[0][d], h = red[0][3 + d];
+            for (int w = 1; w < 16; ++w) { l = fminf(l, red[w][d]); h = fmaxf(h, red[w][3 + d]); }
+            blo[d] = l;
+            ext[d] = h - l;
+            if (!(ext[d] >= 0.f) || !(ext[d] < INFINITY)) ext[d] = 0.f;      // empty / non-finite axis
+            mx = fmaxf(mx, ext[d]);
+            sbox[d] = l;
         }
-        keys[g] = (int)(spread3(c[0]) | (spread3(c[1]) << 1) | (spread3(c[2]) << 2));
+        int bits[3] = {0, 0, 0};
+        float inv = 0.f;
+        if (mx > 0.f) {
+            float cell = mx / 1024.f;                 // at most 10 bits on the longest axis
+            for (;;) {
+                int tot = 0;
+                for (int d = 0; d < 3; ++d) {
+                    const float cells = ext[d] / cell;
+                    int bt = 0;
+                    while (bt < 10 && (float)(1 << bt) < cells) ++bt;
+                    bits[d] = bt;
+                    tot += bt;
+                }
+                if (tot <= NS_KEY_BITS) break;
+                cell *= 2.f;
+            }
+            inv = 1.f / cell;
+        }
+        sbox[3] = inv;
+        for (int d = 0; d < 3; ++d) sbits[d] = bits[d];
     }
+    __syncthreads();
+    const float b0 = sbox[0], b1 = sbox[1], b2 = sbox[2], inv = sbox[3];
+    const int t0 = sbits[0], t1 = sbits[1], t2 = sbits[2];
+    const bool known = blockIdx.x != 0;
+    const float *pts = known ? k : a;
+    const int np = known ? m : n;
+    int *list = known ? list_k + (size_t)bi * m : list_q + (size_t)bi * n;
+    auto key_of = [&](int i) {
+        const float *p = pts + (size_t)i * 3;
+        const float f0 = (p[0] - b0) * inv, f1 = (p[1] - b1) * inv, f2 = (p[2] - b2) * inv;
+        const int q0 = f0 > 0.f ? (int)fminf(f0, (float)((1 << t0) - 1)) : 0;      // NaN -> 0
+        const int q1 = f1 > 0.f ? (int)fminf(f1, (float)((1 << t1) - 1)) : 0;
+        const int q2 = f2 > 0.f ? (int)fminf(f2, (float)((1 << t2) - 1)) : 0;
+        int key = 0, pos = 0;
+        for (int lv = 0; lv < 10; ++lv) {
+            if (lv < t0) { key |= ((q0 >> lv) & 1) << pos; ++pos; }
+            if (lv < t1) { key |= ((q1 >> lv) & 1) << pos; ++pos; }
+            if (lv < t2) { key |= ((q2 >> lv) & 1) << pos; ++pos; }
+        }
+        return key;
+    };
+    for (int i = tid; i < np; i += 1024) atomicAdd(&hist[key_of(i)], 1);
+    __syncthreads();
+    // exclusive scan of the histogram in place: 32 consecutive bins per thread
+    constexpr int PER = NS_CELLS / 1024;
+    int sum = 0;
+    for (int c = 0; c < PER; ++c) sum += hist[tid * PER + c];
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    for (int c = 0; c < PER; ++c) {
+        const int h = hist[tid * PER + c];
+        hist[tid * PER + c] = run;
+        run += h;
+    }
+    __syncthreads();
+    for (int i = tid; i < np; i += 1024) list[atomicAdd(&hist[key_of(i)], 1)] = i;
 }
 
 // ---- 3. sorted known points (x, y, z, original index) and their tile boxes -----------------
-// one wave per tile of 64 sorted known points; tiles never straddle a chunk of NS_CHUNK
+// one wave per tile of 64 sorted known points
 __global__ __launch_bounds__(256) void ns_tile_kernel(int m, int tiles_per_cloud, long long total_tiles,
                                                       const float *__restrict__ xyz2,
                                                       const int *__restrict__ sorted,     // (b, m)
@@ -120,7 +161,13 @@ __global__ __launch_bounds__(256) void ns_tile_kernel(int m, int tiles_per_cloud
         const float *q = xyz2 + ((size_t)bi * m + k) * 3;
         p = make_float4(q[0], q[1], q[2], __builtin_bit_cast(float, k));
     }
-    kp[bi * tiles_per_cloud * 64 + s] = p;
+    // pair layout: entry 2j = (x_2j, x_2j+1, y_2j, y_2j+1), entry 2j+1 = (z_2j, z_2j+1, idx_2j, idx_2j+1),
+    // so that the search runs two candidates through every packed-fp32 operation
+    {
+        const float ox = __shfl_xor(p.x, 1), oy = __shfl_xor(p.y, 1), oz = __shfl_xor(p.z, 1), ow = __shfl_xor(p.w, 1);
+        const float4 e = (lane & 1) ? make_float4(oz, p.z, ow, p.w) : make_float4(p.x, ox, p.y, oy);
+        kp[bi * tiles_per_cloud * 64 + s] = e;
+    }
     float lo[3] = {p.x, p.y, p.z}, hi[3] = {p.x, p.y, p.z};
     if (!(s < m)) {
         for (int d = 0; d < 3; ++d) { lo[d] = INFINITY; hi[d] = -INFINITY; }
@@ -138,10 +185,15 @@ __global__ __launch_bounds__(256) void ns_tile_kernel(int m, int tiles_per_cloud
     }
 }
 
-__device__ __forceinline__ float sqd(const float4 p, float x1, float y1, float z1)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// two candidates (pair layout of ns_tile_kernel) against one query; each component is the
+// scalar computation of tf_interpolate.cpp:73, unfused
+__device__ __forceinline__ f32x2 sqd2(const float4 a, const float4 b, f32x2 qx, f32x2 qy, f32x2 qz)
 {
-    const float dx = p.x - x1, dy = p.y - y1, dz = p.z - z1;
-    return dx * dx + dy * dy + dz * dz;               // tf_interpolate.cpp:73, unfused
+    const f32x2 px = {a.x, a.y}, py = {a.z, a.w}, pz = {b.x, b.y};
+    const f32x2 dx = px - qx, dy = py - qy, dz = pz - qz;
+    return dx * dx + dy * dy + dz * dz;
 }
 
 __device__ __forceinline__ float wave_minf(float v)
@@ -175,11 +227,15 @@ __global__ __launch_bounds__(NS_THREADS) void ns_search_kernel(
     float *__restrict__ out, long long ldo, float *__restrict__ dist, int *__restrict__ idx)
 {
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
-    __shared__ float4 tile[NS_CHUNK];
+    // Waves are independent: each stages the tile it visits in its own 1 KB of LDS (no
+    // workgroup barrier anywhere in the search, so a wave with many tiles to visit never
+    // holds up its neighbours).
+    __shared__ float4 wtile[NS_THREADS / 64][64];
     __shared__ int s_q[NS_THREADS];
     __shared__ int s_i[NS_THREADS * 3];
     __shared__ float s_w[NS_THREADS * 3];
     const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bi = blockIdx.y;
     const int j0 = blockIdx.x * NS_THREADS;
     const int js = j0 + tid;                       // position in sorted order
@@ -192,50 +248,48 @@ __global__ __launch_bounds__(NS_THREADS) void ns_search_kernel(
     const float qhi0 = wave_maxf(x1), qhi1 = wave_maxf(y1), qhi2 = wave_maxf(z1);
     const float4 *kpc = kp + (size_t)bi * tiles_per_cloud * 64;
     const float *tbc = tb + (size_t)bi * tiles_per_cloud * 8;
+    float4 *tp = wtile[wave];
+    const f32x2 qx = {x1, x1}, qy = {y1, y1}, qz = {z1, z1};
     Top3K t = top3k_init();
-    const int mpad = tiles_per_cloud * 64;
-    for (int base = 0; base < mpad; base += NS_CHUNK) {
-        const int tn = min(NS_CHUNK, mpad - base);           // multiple of 64
-        __syncthreads();
-        for (int k = tid; k < tn; k += NS_THREADS) tile[k] = kpc[base + k];
-        __syncthreads();
-        // lane l: lower bound between the wave's query box and tile l of this chunk
-        const int nt = tn / 64;
+    for (int tbase = 0; tbase < tiles_per_cloud; tbase += 64) {
+        // lane l: lower bound between the wave's query box and tile tbase + l
+        const int nt = min(64, tiles_per_cloud - tbase);
         float lb = INFINITY;
         if (lane < nt) {
-            const float *bx = tbc + (size_t)(base / 64 + lane) * 8;
+            const float *bx = tbc + (size_t)(tbase + lane) * 8;
             const float g0 = fmaxf(fmaxf(bx[0] - qhi0, qlo0 - bx[3]), 0.f);
             const float g1 = fmaxf(fmaxf(bx[1] - qhi1, qlo1 - bx[4]), 0.f);
             const float g2 = fmaxf(fmaxf(bx[2] - qhi2, qlo2 - bx[5]), 0.f);
-            lb = g0 * g0 + g1 * g1 + g2 * g2;                // same op order as sqd(): unfused
+            lb = g0 * g0 + g1 * g1 + g2 * g2;                // same op order as sqd2(): unfused
             if (!(lb == lb)) lb = 0.f;                        // NaN box: never skip
         }
         int lbi = lane < nt ? f2i(lb) : 0x7fffffff;           // lb >= 0: int order = float order
         for (;;) {
-            // nearest unvisited tile of the chunk
-            int mn = lbi;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
+            // nearest unvisited tile of the group (DPP reductions: no LDS round trips)
+            const int mn = -wave_max_i32(-lbi);
             if (mn == 0x7fffffff) break;
-            const float worst = wave_maxf(ok ? t.d3 : 0.f);
-            if (i2f(mn) > worst) break;                       // every remaining tile is farther
+            const int worst = wave_max_i32(ok ? f2i(t.d3) : 0);   // distances >= +0: int order
+            if (mn > worst) break;                            // every remaining tile is farther
             const unsigned long long who = __ballot(lbi == mn);
             const int tl = __builtin_ctzll(who);
             if (lane == tl) lbi = 0x7fffffff;
-            const float4 *tp = tile + tl * 64;
+            __builtin_amdgcn_wave_barrier();                  // previous tile fully consumed
+            tp[lane] = kpc[(size_t)(tbase + tl) * 64 + lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll 4
             for (int k = 0; k < 64; k += 4) {
-                const float4 p0 = tp[k], p1 = tp[k + 1], p2 = tp[k + 2], p3 = tp[k + 3];
-                const float d0 = sqd(p0, x1, y1, z1), d1 = sqd(p1, x1, y1, z1);
-                const float d2 = sqd(p2, x1, y1, z1), d3 = sqd(p3, x1, y1, z1);
-                const float mn4 = fminf(fminf(d0, d1), fminf(d2, d3));
+                const float4 a0 = tp[k], b0 = tp[k + 1], a1 = tp[k + 2], b1 = tp[k + 3];
+                const f32x2 da = sqd2(a0, b0, qx, qy, qz), db = sqd2(a1, b1, qx, qy, qz);
+                const float mn4 = fminf(fminf(da[0], da[1]), fminf(db[0], db[1]));
                 // '<=': tiles are not visited in index order, an equal distance with a smaller
                 // index must still get in (the 64-bit key decides)
                 if (__builtin_amdgcn_ballot_w64(mn4 <= t.d3)) {
-                    if (__builtin_amdgcn_ballot_w64(d0 <= t.d3)) top3k_insert(t, d0, f2i(p0.w));
-                    if (__builtin_amdgcn_ballot_w64(d1 <= t.d3)) top3k_insert(t, d1, f2i(p1.w));
-                    if (__builtin_amdgcn_ballot_w64(d2 <= t.d3)) top3k_insert(t, d2, f2i(p2.w));
-                    if (__builtin_amdgcn_ballot_w64(d3 <= t.d3)) top3k_insert(t, d3, f2i(p3.w));
+                    if (__builtin_amdgcn_ballot_w64(da[0] <= t.d3)) top3k_insert(t, da[0], f2i(b0.z));
+                    if (__builtin_amdgcn_ballot_w64(da[1] <= t.d3)) top3k_insert(t, da[1], f2i(b0.w));
+                    if (__builtin_amdgcn_ballot_w64(db[0] <= t.d3)) top3k_insert(t, db[0], f2i(b1.z));
+                    if (__builtin_amdgcn_ballot_w64(db[1] <= t.d3)) top3k_insert(t, db[1], f2i(b1.w));
                 }
             }
         }
@@ -268,10 +322,8 @@ __global__ __launch_bounds__(NS_THREADS) void ns_search_kernel(
 
 // ---- workspace ---------------------------------------------------------------------------
 struct NsWs {
-    float *bbox;      // (b, 8)
-    int *keys_q;      // (b, n)
-    int *keys_k;      // (b, m)
-    void *csr_q, *csr_k;
+    int *list_q;      // (b, n) query indices in grid order
+    int *list_k;      // (b, m)
     float4 *kp;       // (b, tiles*64)
     float *tb;        // (b, tiles, 8)
     size_t bytes;
@@ -285,11 +337,8 @@ static NsWs ns_carve(void *ws, long long b, long long n, long long m)
     char *p = reinterpret_cast<char *>(ws);
     size_t o = 0;
     NsWs w;
-    w.bbox = reinterpret_cast<float *>(p + o); o += up256((size_t)b * 8 * 4);
-    w.keys_q = reinterpret_cast<int *>(p + o); o += up256((size_t)b * n * 4);
-    w.keys_k = reinterpret_cast<int *>(p + o); o += up256((size_t)b * m * 4);
-    w.csr_q = p + o; o += up256(csr_ws_ints(b, NS_CELLS, n) * 4);
-    w.csr_k = p + o; o += up256(csr_ws_ints(b, NS_CELLS, m) * 4);
+    w.list_q = reinterpret_cast<int *>(p + o); o += up256((size_t)b * n * 4);
+    w.list_k = reinterpret_cast<int *>(p + o); o += up256((size_t)b * m * 4);
     w.kp = reinterpret_cast<float4 *>(p + o); o += up256((size_t)b * tiles * 64 * 16);
     w.tb = reinterpret_cast<float *>(p + o); o += up256((size_t)b * tiles * 8 * 4);
     w.bytes = o;
@@ -303,32 +352,22 @@ static int ns_run(int b, int n, int m, int c, const float *xyz1, const float *xy
     if (!ws || ws_bytes < w.bytes) return PRCNN_WORKSPACE;
     if (((uintptr_t)ws & 255) != 0) return PRCNN_BAD_ARG;
     const int tiles = (m + 63) / 64;
-    hipLaunchKernelGGL(ns_bbox_kernel, dim3(b), dim3(1024), 0, st, n, m, xyz1, xyz2, w.bbox);
-    const long long tq = (long long)b * n, tk = (long long)b * m;
-    hipLaunchKernelGGL(ns_key_kernel, dim3((unsigned)((tq + 255) / 256 > 4096 ? 4096 : (tq + 255) / 256)), dim3(256), 0,
-                       st, tq, n, xyz1, w.bbox, w.keys_q);
-    hipLaunchKernelGGL(ns_key_kernel, dim3((unsigned)((tk + 255) / 256 > 4096 ? 4096 : (tk + 255) / 256)), dim3(256), 0,
-                       st, tk, m, xyz2, w.bbox, w.keys_k);
-    CsrWs cq = csr_carve(w.csr_q, b, NS_CELLS, n), ck = csr_carve(w.csr_k, b, NS_CELLS, m);
-    int rc = csr_build(b, NS_CELLS, n, w.keys_q, cq, false, st);
-    if (rc != PRCNN_OK) return rc;
-    rc = csr_build(b, NS_CELLS, m, w.keys_k, ck, false, st);
-    if (rc != PRCNN_OK) return rc;
+    hipLaunchKernelGGL(ns_sort_kernel, dim3(2, b), dim3(1024), 0, st, n, m, xyz1, xyz2, w.list_q, w.list_k);
     const long long total_tiles = (long long)b * tiles;
     hipLaunchKernelGGL(ns_tile_kernel, dim3((unsigned)((total_tiles + 3) / 4)), dim3(256), 0, st, m, tiles,
-                       total_tiles, xyz2, ck.list, w.kp, w.tb);
+                       total_tiles, xyz2, w.list_k, w.kp, w.tb);
     dim3 grid((n + NS_THREADS - 1) / NS_THREADS, b);
     if (!points2) {
         hipLaunchKernelGGL((ns_search_kernel<1, false>), grid, dim3(NS_THREADS), 0, st, n, m, 0, tiles, xyz1,
-                           cq.list, w.kp, w.tb, nullptr, nullptr, 0ll, dist, idx);
+                           w.list_q, w.kp, w.tb, nullptr, nullptr, 0ll, dist, idx);
     } else {
         const bool a16 = (((uintptr_t)points2 | (uintptr_t)out) & 15) == 0 && ldo % 4 == 0;
         if (c % 4 == 0 && a16)
             hipLaunchKernelGGL((ns_search_kernel<4, true>), grid, dim3(NS_THREADS), 0, st, n, m, c, tiles, xyz1,
-                               cq.list, w.kp, w.tb, points2, out, ldo, dist, idx);
+                               w.list_q, w.kp, w.tb, points2, out, ldo, dist, idx);
         else
             hipLaunchKernelGGL((ns_search_kernel<1, true>), grid, dim3(NS_THREADS), 0, st, n, m, c, tiles, xyz1,
-                               cq.list, w.kp, w.tb, points2, out, ldo, dist, idx);
+                               w.list_q, w.kp, w.tb, points2, out, ldo, dist, idx);
     }
     PRCNN_LAUNCH_CHECK();
     return PRCNN_OK;

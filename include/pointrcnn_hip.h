@@ -218,6 +218,17 @@ int prcnn_three_nn_interpolate_sorted(int b, int n, int m, int c, const float *x
                                       int64_t ldo, float *dist, int *idx, void *workspace,
                                       size_t workspace_bytes, prcnn_stream_t stream);
 
+/* prcnn_query_ball_point_msg with the spatially culled search (additive; identical idx /
+ * pts_cnt): points are bucketed and tiled, a wave of four neighbouring centroids visits only
+ * tiles within the largest radius, and the per-ball hits are reduced to the nsample smallest
+ * indices in ascending order.  nsample <= 64 per scale.  workspace as above. */
+size_t prcnn_query_ball_point_sorted_workspace_bytes(int b, int n, int m);
+int prcnn_query_ball_point_msg_sorted(int b, int n, int m, int nscales, const float *host_radii,
+                                      const int *host_nsamples, const float *xyz1,
+                                      const float *xyz2, int *const *host_idx,
+                                      int *const *host_pts_cnt, void *workspace,
+                                      size_t workspace_bytes, prcnn_stream_t stream);
+
 /* ---- backward ops ------------------------------------------------
  * All three are ordered segmented reductions: every output element is summed in exactly
  * the order of the reference's serial CPU loops, so results are deterministic and equal

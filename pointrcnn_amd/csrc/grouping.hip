@@ -18,6 +18,7 @@
 // stores are fully coalesced and each gathered row is read in contiguous pieces.
 #include <math.h>
 #include "common.h"
+#include "ball.h"
 
 namespace prcnn {
 
@@ -27,13 +28,6 @@ constexpr int BQ_CPW = 4;                         // centroids per wave
 constexpr int BQ_CPB = BQ_WAVES * BQ_CPW;         // centroids per workgroup
 constexpr int BQ_TILE = 2048;                     // candidate points per LDS tile
 
-struct BallScales {            // up to BQ_MAX_SCALES radii evaluated in one pass (MSG grouping)
-    float thr2[4];
-    int nsample[4];
-    int *idx[4];
-    int *pts_cnt[4];
-};
-constexpr int BQ_MAX_SCALES = 4;
 
 template <int NS>
 __global__ __launch_bounds__(BQ_THREADS) void ball_query_kernel(int n, int m, const BallScales sc,
@@ -194,7 +188,7 @@ __global__ __launch_bounds__(256) void group_point_kernel(int n, int c, long lon
 
 // smallest float t such that max(sqrtf(t), 1e-20f) >= radius, i.e. the reference's
 // test  max(sqrtf(d2),1e-20f) < radius  <=>  d2 < t   for every float d2 >= 0.
-static float ball_threshold(float radius)
+float ball_threshold(float radius)
 {
     if (!(radius > 1e-20f)) return 0.0f;            // d >= 1e-20 >= radius: nothing passes
     float t = (float)((double)radius * (double)radius);

@@ -16,6 +16,7 @@
 // index order equals "three smallest by (distance, index)"; since tiles are not visited
 // in index order, insertion here compares (distance, index) pairs lexicographically.
 #include "common.h"
+#include "ball.h"
 
 namespace prcnn {
 
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(1024) void ns_sort_kernel(int n, int m, const float
 
 // ---- 3. sorted known points (x, y, z, original index) and their tile boxes -----------------
 // one wave per tile of 64 sorted known points
+template <bool PAIR>
 __global__ __launch_bounds__(256) void ns_tile_kernel(int m, int tiles_per_cloud, long long total_tiles,
                                                       const float *__restrict__ xyz2,
                                                       const int *__restrict__ sorted,     // (b, m)
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void ns_tile_kernel(int m, int tiles_per_cloud
     {
         const float ox = __shfl_xor(p.x, 1), oy = __shfl_xor(p.y, 1), oz = __shfl_xor(p.z, 1), ow = __shfl_xor(p.w, 1);
         const float4 e = (lane & 1) ? make_float4(oz, p.z, ow, p.w) : make_float4(p.x, ox, p.y, oy);
-        kp[bi * tiles_per_cloud * 64 + s] = e;
+        kp[bi * tiles_per_cloud * 64 + s] = PAIR ? e : p;        // !PAIR: (x, y, z, idx) per point
     }
     float lo[3] = {p.x, p.y, p.z}, hi[3] = {p.x, p.y, p.z};
     if (!(s < m)) {
@@ -354,7 +356,7 @@ static int ns_run(int b, int n, int m, int c, const float *xyz1, const float *xy
     const int tiles = (m + 63) / 64;
     hipLaunchKernelGGL(ns_sort_kernel, dim3(2, b), dim3(1024), 0, st, n, m, xyz1, xyz2, w.list_q, w.list_k);
     const long long total_tiles = (long long)b * tiles;
-    hipLaunchKernelGGL(ns_tile_kernel, dim3((unsigned)((total_tiles + 3) / 4)), dim3(256), 0, st, m, tiles,
+    hipLaunchKernelGGL(ns_tile_kernel<true>, dim3((unsigned)((total_tiles + 3) / 4)), dim3(256), 0, st, m, tiles,
                        total_tiles, xyz2, w.list_k, w.kp, w.tb);
     dim3 grid((n + NS_THREADS - 1) / NS_THREADS, b);
     if (!points2) {
@@ -368,6 +370,161 @@ static int ns_run(int b, int n, int m, int c, const float *xyz1, const float *xy
         else
             hipLaunchKernelGGL((ns_search_kernel<1, true>), grid, dim3(NS_THREADS), 0, st, n, m, c, tiles, xyz1,
                                w.list_q, w.kp, w.tb, points2, out, ldo, dist, idx);
+    }
+    PRCNN_LAUNCH_CHECK();
+    return PRCNN_OK;
+}
+
+// ---- 5. ball query over the same grid ---------------------------------------------------------
+// query_ball_point (tf_grouping_g.cu:3-36): the first nsample point indices, in index order,
+// with max(sqrt(d2),1e-20) < radius, i.e. d2 < thr2 (ball_threshold).  Here the POINTS are
+// bucketed and tiled; a wave owns four neighbouring centroids and visits only the tiles whose
+// box comes closer than the largest radius to the box of its centroids (same rounding-monotone
+// bound as above: a skipped tile cannot contain a hit).  Hits arrive in arbitrary index order,
+// so every (centroid, scale) keeps a small LDS buffer that is reduced to its nsample smallest
+// indices, ascending (rank counting), whenever it would overflow and once at the end:
+// identical rows, padding and pts_cnt as the index-order scan.
+constexpr int BC_CPW = 4;
+constexpr int BC_BUF = 128;
+
+// keep the min(L, ns) smallest of the L (<= 128, distinct) entries of b, ascending
+__device__ __forceinline__ int bc_compact(int *b, int L, int ns, int lane)
+{
+    const int e0 = lane < L ? b[lane] : 0x7fffffff;
+    const int e1 = lane + 64 < L ? b[lane + 64] : 0x7fffffff;
+    int r0 = 0, r1 = 0;
+    for (int u = 0; u < L; ++u) {
+        const int v = b[u];
+        r0 += v < e0 ? 1 : 0;
+        r1 += v < e1 ? 1 : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < L && r0 < ns) b[r0] = e0;
+    if (lane + 64 < L && r1 < ns) b[r1] = e1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return min(L, ns);
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void bq_culled_kernel(int n, int m, int tiles, const BallScales sc,
+                                                        const float *__restrict__ xyz2,
+                                                        const int *__restrict__ csorted,   // (b, m)
+                                                        const float4 *__restrict__ pp,     // (b, tiles*64)
+                                                        const float *__restrict__ tb)      // (b, tiles, 8)
+{
+    __shared__ int buf[4][BC_CPW][NS][BC_BUF];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bi = blockIdx.y;
+    const int j0 = (blockIdx.x * 4 + wave) * BC_CPW;
+    if (j0 >= m) return;
+    int cj[BC_CPW];
+    float cx[BC_CPW], cy[BC_CPW], cz[BC_CPW];
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int c = 0; c < BC_CPW; ++c) {
+        const int js = min(j0 + c, m - 1);                   // past the end: repeat the last one
+        cj[c] = j0 + c < m ? csorted[(size_t)bi * m + js] : -1;
+        const float *p = xyz2 + ((size_t)bi * m + csorted[(size_t)bi * m + js]) * 3;
+        cx[c] = p[0]; cy[c] = p[1]; cz[c] = p[2];
+        clo[0] = fminf(clo[0], cx[c]); chi[0] = fmaxf(chi[0], cx[c]);
+        clo[1] = fminf(clo[1], cy[c]); chi[1] = fmaxf(chi[1], cy[c]);
+        clo[2] = fminf(clo[2], cz[c]); chi[2] = fmaxf(chi[2], cz[c]);
+    }
+    float thrmax = sc.thr2[0];
+#pragma unroll
+    for (int s = 1; s < NS; ++s) thrmax = fmaxf(thrmax, sc.thr2[s]);
+    int cnt[BC_CPW][NS], tot[BC_CPW][NS];
+#pragma unroll
+    for (int c = 0; c < BC_CPW; ++c)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { cnt[c][s] = 0; tot[c][s] = 0; }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const float4 *ppc = pp + (size_t)bi * tiles * 64;
+    const float *tbc = tb + (size_t)bi * tiles * 8;
+    for (int tbase = 0; tbase < tiles; tbase += 64) {
+        const int nt = min(64, tiles - tbase);
+        bool cand = false;
+        if (lane < nt) {
+            const float *bx = tbc + (size_t)(tbase + lane) * 8;
+            const float g0 = fmaxf(fmaxf(bx[0] - chi[0], clo[0] - bx[3]), 0.f);
+            const float g1 = fmaxf(fmaxf(bx[1] - chi[1], clo[1] - bx[4]), 0.f);
+            const float g2 = fmaxf(fmaxf(bx[2] - chi[2], clo[2] - bx[5]), 0.f);
+            const float lb = g0 * g0 + g1 * g1 + g2 * g2;    // same op order as the distance: unfused
+            cand = !(lb >= thrmax);                          // NaN bound: visit
+        }
+        unsigned long long todo = __ballot(cand);
+        while (todo) {
+            const int tl = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float4 p = ppc[(size_t)(tbase + tl) * 64 + lane];   // NaN padding never hits
+            const int k = f2i(p.w);
+            const f32x2 px = {p.x, p.x}, py = {p.y, p.y}, pz = {p.z, p.z};
+#pragma unroll
+            for (int c0 = 0; c0 < BC_CPW; c0 += 2) {
+                const f32x2 ccx = {cx[c0], cx[c0 + 1]}, ccy = {cy[c0], cy[c0 + 1]}, ccz = {cz[c0], cz[c0 + 1]};
+                const f32x2 dx = ccx - px, dy = ccy - py, dz = ccz - pz;
+                const f32x2 d2p = dx * dx + dy * dy + dz * dz;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int c = c0 + h;
+                    if (__builtin_amdgcn_ballot_w64(d2p[h] < thrmax) == 0) continue;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        const bool hit = d2p[h] < sc.thr2[s];
+                        const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
+                        if (hm == 0) continue;
+                        const int nh = __builtin_popcountll(hm);
+                        int *bb = buf[wave][c][s];
+                        if (cnt[c][s] + nh > BC_BUF) cnt[c][s] = bc_compact(bb, cnt[c][s], sc.nsample[s], lane);
+                        if (hit) bb[cnt[c][s] + __builtin_popcountll(hm & lt)] = k;
+                        cnt[c][s] += nh;
+                        tot[c][s] += nh;
+                    }
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < BC_CPW; ++c) {
+        if (cj[c] < 0) continue;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int ns = sc.nsample[s];
+            int *bb = buf[wave][c][s];
+            const int cc = bc_compact(bb, cnt[c][s], ns, lane);
+            int *row = sc.idx[s] + ((size_t)bi * m + cj[c]) * ns;
+            // rows are padded with the first (smallest) index, rows without a hit are zero-filled
+            const int fill = cc > 0 ? bb[0] : 0;
+            for (int l = lane; l < ns; l += 64) row[l] = l < cc ? bb[l] : fill;
+            if (sc.pts_cnt[s] && lane == 0) sc.pts_cnt[s][(size_t)bi * m + cj[c]] = cc;
+        }
+    }
+}
+
+static int bq_run(int b, int n, int m, int nscales, const BallScales &sc, const float *xyz1, const float *xyz2,
+                  void *ws, size_t ws_bytes, hipStream_t st)
+{
+    // queries = centroids (m), known = points (n)
+    NsWs w = ns_carve(ws, b, m, n);
+    if (!ws || ws_bytes < w.bytes) return PRCNN_WORKSPACE;
+    if (((uintptr_t)ws & 255) != 0) return PRCNN_BAD_ARG;
+    const int tiles = (n + 63) / 64;
+    hipLaunchKernelGGL(ns_sort_kernel, dim3(2, b), dim3(1024), 0, st, m, n, xyz2, xyz1, w.list_q, w.list_k);
+    const long long total_tiles = (long long)b * tiles;
+    hipLaunchKernelGGL(ns_tile_kernel<false>, dim3((unsigned)((total_tiles + 3) / 4)), dim3(256), 0, st, n, tiles,
+                       total_tiles, xyz1, w.list_k, w.kp, w.tb);
+    dim3 grid((m + 4 * BC_CPW - 1) / (4 * BC_CPW), b);
+    switch (nscales) {
+        case 1: hipLaunchKernelGGL(bq_culled_kernel<1>, grid, dim3(256), 0, st, n, m, tiles, sc, xyz2, w.list_q, w.kp, w.tb); break;
+        case 2: hipLaunchKernelGGL(bq_culled_kernel<2>, grid, dim3(256), 0, st, n, m, tiles, sc, xyz2, w.list_q, w.kp, w.tb); break;
+        case 3: hipLaunchKernelGGL(bq_culled_kernel<3>, grid, dim3(256), 0, st, n, m, tiles, sc, xyz2, w.list_q, w.kp, w.tb); break;
+        default: hipLaunchKernelGGL(bq_culled_kernel<4>, grid, dim3(256), 0, st, n, m, tiles, sc, xyz2, w.list_q, w.kp, w.tb); break;
     }
     PRCNN_LAUNCH_CHECK();
     return PRCNN_OK;
@@ -404,4 +561,38 @@ extern "C" int prcnn_three_nn_interpolate_sorted(int b, int n, int m, int c, con
     if (b > 65535) return PRCNN_UNSUPPORTED;
     return prcnn::ns_run(b, n, m, c, xyz1, xyz2, points2, out, ldo, dist, idx, workspace, workspace_bytes,
                          to_stream(stream));
+}
+
+extern "C" size_t prcnn_query_ball_point_sorted_workspace_bytes(int b, int n, int m)
+{
+    if (b <= 0 || n <= 0 || m <= 0) return 0;
+    return prcnn::ns_carve(nullptr, b, m, n).bytes;
+}
+
+extern "C" int prcnn_query_ball_point_msg_sorted(int b, int n, int m, int nscales, const float *host_radii,
+                                                 const int *host_nsamples, const float *xyz1,
+                                                 const float *xyz2, int *const *host_idx,
+                                                 int *const *host_pts_cnt, void *workspace,
+                                                 size_t workspace_bytes, prcnn_stream_t stream)
+{
+    using namespace prcnn;
+    if (nscales < 1 || nscales > BQ_MAX_SCALES) return PRCNN_UNSUPPORTED;
+    if (!host_radii || !host_nsamples || !host_idx) return PRCNN_BAD_SHAPE;
+    BallScales sc = {};
+    for (int s = 0; s < nscales; ++s) {
+        if (!(host_radii[s] > 0.0f)) return PRCNN_BAD_ARG;       // tf_grouping.cpp:71
+        if (host_nsamples[s] <= 0) return PRCNN_BAD_ARG;         // tf_grouping.cpp:74
+        if (host_nsamples[s] > 64) return PRCNN_UNSUPPORTED;     // LDS buffer = 2 x 64 entries
+        sc.thr2[s] = ball_threshold(host_radii[s]);
+        sc.nsample[s] = host_nsamples[s];
+        sc.idx[s] = host_idx[s];
+        sc.pts_cnt[s] = host_pts_cnt ? host_pts_cnt[s] : nullptr;
+    }
+    if (b < 0 || n <= 0 || m < 0) return PRCNN_BAD_SHAPE;
+    if (b == 0 || m == 0) return PRCNN_OK;
+    if (!xyz1 || !xyz2) return PRCNN_BAD_SHAPE;
+    for (int s = 0; s < nscales; ++s)
+        if (!sc.idx[s]) return PRCNN_BAD_SHAPE;
+    if (b > 65535) return PRCNN_UNSUPPORTED;
+    return bq_run(b, n, m, nscales, sc, xyz1, xyz2, workspace, workspace_bytes, to_stream(stream));
 }

@@ -259,3 +259,30 @@ def test_three_nn_culled_search_is_bit_identical(cuda):
             assert torch.equal(d0, d1) and torch.equal(i0, i1) and torch.equal(o0, o1)
     finally:
         ops.NN_SORTED_MIN_TESTS, ops.NN_SORTED_MIN_M = saved
+
+
+def test_ball_query_culled_search_is_identical(cuda):
+    """prcnn_query_ball_point_msg_sorted (additive entry point): same idx / pts_cnt as the
+    index-order scan, including balls that overflow the per-ball LDS buffer, nsample 64,
+    empty balls, lattice ties and identical points."""
+    g = torch.Generator().manual_seed(1)
+    pc = torch.as_tensor(S.kitti_batch(0, 2)).to(cuda)
+    xyz = pc[:, :, :3].contiguous()
+    x2 = ops.gather_point(xyz, ops.farthest_point_sample(1024, xyz))
+    uni = torch.rand(3, 5000, 3, generator=g).to(cuda)
+    cen = torch.rand(3, 333, 3, generator=g).to(cuda)
+    lat = torch.randint(0, 5, (2, 4000, 3), generator=g).float().to(cuda)
+    cases = [([0.1, 0.5], [16, 32], xyz, x2), ([2.0, 4.0], [16, 32], xyz, x2), ([0.5], [64], xyz, x2),
+             ([0.05, 0.2, 0.4], [8, 16, 33], uni, cen), ([1.0, 1.5], [16, 64], lat, lat[:, :100].contiguous()),
+             ([0.3], [4], torch.zeros(1, 300, 3, device=cuda), torch.zeros(1, 5, 3, device=cuda))]
+    saved = ops.BQ_SORTED_MIN_TESTS
+    try:
+        for radii, nss, a, c in cases:
+            ops.BQ_SORTED_MIN_TESTS = None
+            ref = ops.query_ball_point_msg(radii, nss, a, c)
+            ops.BQ_SORTED_MIN_TESTS = 0
+            got = ops.query_ball_point_msg(radii, nss, a, c)
+            for (i0, c0), (i1, c1) in zip(ref, got):
+                assert torch.equal(i0, i1) and torch.equal(c0, c1)
+    finally:
+        ops.BQ_SORTED_MIN_TESTS = saved

@@ -264,6 +264,17 @@ int prcnn_three_interpolate_grad(int b, int n, int c, int m, const float *grad_o
                                  const float *weight, float *grad_points, void *workspace,
                                  size_t workspace_bytes, prcnn_stream_t stream);
 
+/* ---- scene-sharded harness (no counterpart in the reference, which is
+ * single-GPU) ---------------------------------------------------------------------------------
+ * One float32 record per scene for the per-step all-gather:
+ *   rec[s] = [scene_ids[s], n_keep[s], max_det x (boxes3d[s, keep[s,d], 0:7], scores[s, keep[s,d]])]
+ * with zeros past n_keep[s].  boxes3d (scenes,nprop,7) f64, scores (scenes,nprop) f64,
+ * keep (scenes,max_det) int64 and n_keep (scenes) int32 as produced by
+ * prcnn_nms_rotate_batched; rec (scenes, 2 + 8*max_det) f32. */
+int prcnn_pack_detections(int scenes, int nprop, int max_det, const float *scene_ids,
+                          const double *boxes3d, const double *scores, const int64_t *keep,
+                          const int *n_keep, float *rec, prcnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,21 @@ def pack_detections(scene_ids, boxes3d, scores, keep, n_keep):
     n_keep (S,) int."""
     S = boxes3d.shape[0]
     dev = boxes3d.device
+    if boxes3d.is_cuda:
+        # one HIP launch (prcnn_pack_detections); the torch composition below serves host tensors
+        from . import _lib
+        ids = torch.as_tensor(scene_ids, dtype=torch.float32, device=dev).contiguous()
+        b3 = boxes3d.to(torch.float64).contiguous()
+        sc = scores.to(torch.float64).contiguous()
+        kp = keep.to(torch.int64).contiguous()
+        nk = n_keep.to(torch.int32).contiguous()
+        if kp.shape != (S, MAX_DET):
+            raise ValueError("keep must be (S, %d)" % MAX_DET)
+        rec = torch.empty((S, RECORD_LEN), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().prcnn_pack_detections(S, b3.shape[1], MAX_DET, ids.data_ptr(), b3.data_ptr(),
+                                                    sc.data_ptr(), kp.data_ptr(), nk.data_ptr(), rec.data_ptr(),
+                                                    torch.cuda.current_stream().cuda_stream), "pack_detections")
+        return rec
     valid = torch.arange(MAX_DET, device=dev).unsqueeze(0) < n_keep.view(S, 1)
     k = torch.where(valid, keep, torch.zeros_like(keep))
     b = torch.gather(boxes3d, 1, k.unsqueeze(-1).expand(S, MAX_DET, 7)).to(torch.float32)

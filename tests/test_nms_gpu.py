@@ -71,3 +71,19 @@ def test_score_ties_resolve_to_lower_index(cuda):
     order = np.lexsort((np.arange(200), -scores))               # score desc, index asc
     want = O.nms_rotate_cpu(boxes, scores, 0.5, 100, order=order)
     assert np.array_equal(nms_rotate_cpu(boxes, scores, 0.5, 100), want)
+
+
+def test_pack_detections_kernel_equals_host_composition(cuda):
+    """prcnn_pack_detections (one launch) against dist.pack_detections' torch composition on
+    host tensors, which the world-size-2 gloo test exercises."""
+    from pointrcnn_amd import dist as pdist
+    g = torch.Generator().manual_seed(3)
+    S_, N = 5, 300
+    b3 = torch.randn(S_, N, 7, generator=g, dtype=torch.float64)
+    sc = torch.rand(S_, N, generator=g, dtype=torch.float64)
+    keep = torch.randint(0, N, (S_, pdist.MAX_DET), generator=g)
+    nk = torch.tensor([0, 1, 37, pdist.MAX_DET, 99], dtype=torch.int32)
+    ids = torch.arange(10, 10 + S_, dtype=torch.float32)
+    want = pdist.pack_detections(ids, b3, sc, keep, nk)
+    got = pdist.pack_detections(ids.to(cuda), b3.to(cuda), sc.to(cuda), keep.to(cuda), nk.to(cuda))
+    assert got.is_cuda and torch.equal(got.cpu(), want)

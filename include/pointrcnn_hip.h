@@ -264,6 +264,23 @@ int prcnn_three_interpolate_grad(int b, int n, int c, int m, const float *grad_o
                                  const float *weight, float *grad_points, void *workspace,
                                  size_t workspace_bytes, prcnn_stream_t stream);
 
+/* ---- kNN grouping -------------------------------------------------------
+ * selectionSortLauncher(b,n,m,k,dist,outi,out)  models/tf_ops/grouping/tf_grouping.cpp:106
+ * (kernel selection_sort_gpu tf_grouping_g.cu:83-123, CPU twin selection_sort_cpu
+ * selection_sort.cpp:20-63): dist (b,m,n) -> outi (b,m,n) int32, out (b,m,n) f32, the rows
+ * after k steps of "swap the first minimum of positions s.. to position s" (the first k entries
+ * are the k smallest, ascending; ties in the reference's swap order, reproduced exactly).
+ * 0 < k <= min(n, 128). */
+int prcnn_selection_sort(int b, int n, int m, int k, const float *dist, int *outi, float *out,
+                         prcnn_stream_t stream);
+
+/* knn_point(k, xyz1, xyz2)  models/tf_ops/grouping/tf_grouping.py:49-74, fused: the (b,m,n)
+ * matrix reduce_sum((xyz1-xyz2)**2,-1) is never materialised.  xyz1 (b,n,3) dataset, xyz2
+ * (b,m,3) queries -> val (b,m,k) squared distances ascending, idx (b,m,k) int32; identical to
+ * prcnn_selection_sort on that matrix, sliced to k. */
+int prcnn_knn_point(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val,
+                    int *idx, prcnn_stream_t stream);
+
 /* ---- scene-sharded harness (no counterpart in the reference, which is
  * single-GPU) ---------------------------------------------------------------------------------
  * One float32 record per scene for the per-step all-gather:

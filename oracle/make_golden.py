@@ -80,7 +80,26 @@ def main():
                         cloud=cloud, idx_dup=idx_dup, tie=tie, idx_tie=idx_tie, small=small,
                         idx_small=idx_small)
     grad_golden()
+    knn_golden()
     print("golden vectors written to", os.path.normpath(OUT))
+
+
+def knn_golden():
+    """selection_sort_cpu (selection_sort.cpp:20-63) on small matrices with many exact ties
+    (the tie order is the part that needs pinning) and on a tie-free one."""
+    rng = np.random.default_rng(20251112)
+    d_ties = rng.integers(0, 6, (2, 5, 40)).astype(np.float32)          # heavy ties
+    d_ties[0, 0, :] = 3.0                                               # a constant row
+    d_ties[1, 1, :8] = 9.0                                              # large values in front: displaced
+    d_free = rng.random((1, 4, 64), dtype=np.float32)
+    out = {}
+    for name, d, k in (("ties_k3", d_ties, 3), ("ties_k16", d_ties, 16), ("ties_k40", d_ties, 40),
+                       ("free_k10", d_free, 10)):
+        idx, val = ref.selection_sort_cpu(k, d)
+        out[name + "_idx"] = idx
+        out[name + "_val"] = val
+    np.savez_compressed(os.path.join(OUT, "selection_sort_ref.npz"), source="reference", d_ties=d_ties,
+                        d_free=d_free, **out)
 
 
 def grad_golden():
@@ -110,5 +129,8 @@ if __name__ == "__main__":
     import sys
     if "--grad-only" in sys.argv:
         grad_golden()
+        raise SystemExit(0)
+    if "--knn-only" in sys.argv:
+        knn_golden()
         raise SystemExit(0)
     main()

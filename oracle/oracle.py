@@ -116,6 +116,27 @@ def three_interpolate(points, idx, weight):
     return out
 
 
+def select_top_k(k, dist):
+    """tf_grouping.py:23-32 -> (idx (b,m,n) int32, dist_out (b,m,n) f32)."""
+    dist = _f32(dist)
+    b, m, n = dist.shape
+    idx = np.empty((b, m, n), np.int32)
+    val = np.empty((b, m, n), np.float32)
+    lib().oracle_selection_sort(b, n, m, int(k), _p(dist), _p(idx), _p(val))
+    return idx, val
+
+
+def knn_point(k, xyz1, xyz2):
+    """tf_grouping.py:49-74 -> (val (b,m,k) f32, idx (b,m,k) int32)."""
+    xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    val = np.empty((b, m, int(k)), np.float32)
+    idx = np.empty((b, m, int(k)), np.int32)
+    lib().oracle_knn_point(b, n, m, int(k), _p(xyz1), _p(xyz2), _p(val), _p(idx))
+    return val, idx
+
+
 def gather_point_grad(inp, idx, out_g):
     """Argument order of the reference op GatherPointGrad (tf_sampling.py:44-48): only
     inp's shape is used."""

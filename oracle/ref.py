@@ -79,6 +79,39 @@ def interpolate_cpu(points, idx, weight):
     return out
 
 
+_s = None
+
+
+def _ssort():
+    global _s
+    if _s is None:
+        _s = ctypes.CDLL(os.path.join(_REF, "libref_ssort.so"))
+    return _s
+
+
+def selection_sort_cpu(k, dist):
+    """selection_sort.cpp:20-63.  The reference function printf()s every element and every
+    pick; file descriptor 1 is pointed at /dev/null for the duration of the call.
+    Returns (idx (b,m,n) int32, val (b,m,n) f32)."""
+    dist = np.ascontiguousarray(dist, np.float32)
+    b, m, n = dist.shape
+    idx = np.empty((b, m, n), np.int32)
+    val = np.empty((b, m, n), np.float32)
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    try:
+        os.dup2(devnull, 1)
+        _ssort()._Z18selection_sort_cpuiiiiPKfPiPf(b, n, m, int(k), _p(dist), _p(idx), _p(val))
+        ctypes.CDLL(None).fflush(None)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+        os.close(devnull)
+    return idx, val
+
+
 def group_point_grad_cpu(n, idx, grad_out):
     """query_ball_point.cpp:70-84 (accumulates into a caller-cleared buffer)."""
     idx = np.ascontiguousarray(idx, np.int32)

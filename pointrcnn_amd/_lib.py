@@ -48,6 +48,8 @@ SIGNATURES = {
     "prcnn_three_nn_interpolate_sorted": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "prcnn_query_ball_point_sorted_workspace_bytes": (_sz, [_i, _i, _i]),
     "prcnn_query_ball_point_msg_sorted": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "prcnn_selection_sort": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "prcnn_knn_point": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "prcnn_pack_detections": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "prcnn_gather_point_grad_workspace_bytes": (_sz, [_i, _i, _i]),
     "prcnn_gather_point_grad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

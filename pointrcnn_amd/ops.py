@@ -183,6 +183,41 @@ def query_ball_point_msg(radius_list, nsample_list, xyz1, xyz2):
     return res
 
 
+def select_top_k(k, dist):
+    """tf_grouping.py:23-32 (op SelectionSort).  dist (b,m,n) -> idx (b,m,n) int32,
+    dist_out (b,m,n): the rows after k selection-sort steps (first k = k smallest)."""
+    dist = _dev(dist, torch.float32, "SelectionSort dist", 3)                 # tf_grouping.cpp:118
+    b, m, n = dist.shape
+    if int(k) <= 0:
+        raise ValueError("SelectionSort expects positive k")                  # tf_grouping.cpp:113
+    outi = torch.empty((b, m, n), dtype=torch.int32, device=dist.device)
+    out = torch.empty((b, m, n), dtype=torch.float32, device=dist.device)
+    _lib.check(_run("selection_sort", {"bytes": b * m * n * 12},
+                    lambda: _lib.lib().prcnn_selection_sort(b, n, m, int(k), _p(dist), _p(outi), _p(out), _stream())),
+               "SelectionSort")
+    return outi, out
+
+
+def knn_point(k, xyz1, xyz2):
+    """tf_grouping.py:49-74.  xyz1 (b,n,3) dataset, xyz2 (b,m,3) queries -> val (b,m,k)
+    squared distances, idx (b,m,k) int32 (fused: no (b,m,n) matrix)."""
+    xyz1 = _dev(xyz1, torch.float32, "knn_point xyz1", 3, 3)
+    xyz2 = _dev(xyz2, torch.float32, "knn_point xyz2", 3, 3)
+    if xyz1.shape[0] != xyz2.shape[0]:
+        raise ValueError("knn_point expects equal batch sizes")
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    k = int(k)
+    if k <= 0:
+        raise ValueError("SelectionSort expects positive k")
+    val = torch.empty((b, m, k), dtype=torch.float32, device=xyz1.device)
+    idx = torch.empty((b, m, k), dtype=torch.int32, device=xyz1.device)
+    _lib.check(_run("knn_point", {"tests": b * m * n * 5},
+                    lambda: _lib.lib().prcnn_knn_point(b, n, m, k, _p(xyz1), _p(xyz2), _p(val), _p(idx), _stream())),
+               "knn_point")
+    return val, idx
+
+
 def _group_point_fwd(points, idx):
     """tf_grouping.py:34-42.  points (b,n,c), idx (b,m,nsample) -> (b,m,nsample,c)."""
     points = _dev(points, torch.float32, "GroupPoint points", 3)       # tf_grouping.cpp:147

@@ -93,10 +93,11 @@ def _check_inference(is_training):
 
 def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True):
     """models/pointnet_util.py:21-55 -> new_xyz, new_points, idx, grouped_xyz."""
-    if knn:
-        raise NotImplementedError("knn grouping is never enabled by the reference's callers")
     new_xyz = ops.gather_point(xyz, ops.farthest_point_sample(npoint, xyz))
-    idx, pts_cnt = ops.query_ball_point(radius, nsample, xyz, new_xyz)
+    if knn:
+        _, idx = ops.knn_point(nsample, xyz, new_xyz)                # pointnet_util.py:40-41
+    else:
+        idx, pts_cnt = ops.query_ball_point(radius, nsample, xyz, new_xyz)
     grouped_xyz = ops.group_point(xyz, idx)
     grouped_xyz = grouped_xyz - new_xyz.unsqueeze(2)                 # translation normalisation
     if points is not None:
@@ -135,8 +136,8 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
                        use_nchw=False, params=None, precision=None):
     """models/pointnet_util.py:86-153 -> new_xyz (b,npoint,3), new_points (b,npoint,mlp[-1]), idx."""
     _check_inference(is_training)
-    if pooling != 'max' or mlp2 is not None or knn or use_nchw:
-        raise NotImplementedError("only pooling='max', mlp2=None, knn=False, NHWC are used by the reference")
+    if pooling != 'max' or mlp2 is not None or use_nchw:
+        raise NotImplementedError("only pooling='max', mlp2=None, NHWC are used by the reference")
     store = params if params is not None else get_params()
     precision = PRECISION if precision is None else precision
     b = xyz.shape[0]
@@ -152,7 +153,10 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
     c_feat = 0 if points is None else points.shape[2]
     if FUSED and (use_xyz or points is None) and nsample % 16 == 0 and 128 % nsample == 0:
         new_xyz = ops.gather_point(xyz, ops.farthest_point_sample(npoint, xyz))
-        idx, _ = ops.query_ball_point(radius, nsample, xyz, new_xyz)
+        if knn:
+            _, idx = ops.knn_point(nsample, xyz, new_xyz)            # pointnet_util.py:40-41
+        else:
+            idx, _ = ops.query_ball_point(radius, nsample, xyz, new_xyz)
         if ops.sa_chain_supported(c_feat, mlp, nsample, precision):
             layers = [store.layer('%s/conv%d' % (scope, j), ci, co, bn)
                       for j, (ci, co) in enumerate(zip([c_feat + 3] + list(mlp[:-1]), mlp))]

@@ -75,6 +75,9 @@ def main():
                 us = timeit(lambda: ops.group_point(f, idx), a.iters)
                 by = b * m * ns * (4 + 8 * c)
                 rep("group_point", "b%d m%d ns%d C%d" % (b, m, ns, c), us, by / us / 1e3 / 8000, "%.0f GB/s" % (by / us / 1e3))
+            if want("knn") and r == radii[-1]:
+                us = timeit(lambda: ops.knn_point(ns, x, new_xyz), max(3, a.iters // 4))
+                rep("knn_point", "b%d n%d m%d k%d" % (b, n, m, ns), us, None, "%.1f Gdist/s (5 passes)" % (5 * b * m * n / us / 1e3))
             if want("grad"):
                 go = torch.randn(b, m, ns, c, generator=rng).to(dev)
                 us = timeit(lambda: ops.group_point_grad(f, idx, go), a.iters)

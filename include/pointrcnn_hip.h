@@ -218,6 +218,16 @@ int prcnn_three_nn_interpolate_sorted(int b, int n, int m, int c, const float *x
                                       int64_t ldo, float *dist, int *idx, void *workspace,
                                       size_t workspace_bytes, prcnn_stream_t stream);
 
+/* out[:, :c] = out[:, :c] + interpolate(points2) (then ReLU if relu != 0): the epilogue of the
+ * split FP layer  relu(BN([interp, points1] W)) = relu(interp3((points2 W_a) s) + (points1 W_b) s + t),
+ * which runs the wide half of the first FP convolution on the m known rows instead of the
+ * n = 4m interpolated rows (models/pointnet_util.py:215-226).  workspace: NULL = brute-force
+ * search, else prcnn_three_nn_sorted_workspace_bytes() bytes for the culled search. */
+int prcnn_three_nn_interpolate_add(int b, int n, int m, int c, const float *xyz1,
+                                   const float *xyz2, const float *points2, float *out,
+                                   int64_t ldo, int relu, void *workspace, size_t workspace_bytes,
+                                   prcnn_stream_t stream);
+
 /* prcnn_query_ball_point_msg with the spatially culled search (additive; identical idx /
  * pts_cnt): points are bucketed and tiled, a wave of four neighbouring centroids visits only
  * tiles within the largest radius, and the per-ball hits are reduced to the nsample smallest

@@ -162,7 +162,7 @@ template <int VEC>
 __global__ __launch_bounds__(FU_THREADS) void three_nn_interpolate_kernel(
     int n, int m, int c, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
     const float *__restrict__ points2, float *__restrict__ out, long long ldo,
-    float *__restrict__ dist, int *__restrict__ idx)
+    float *__restrict__ dist, int *__restrict__ idx, int epi)
 {
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
     __shared__ PairTile tile;
@@ -205,8 +205,16 @@ __global__ __launch_bounds__(FU_THREADS) void three_nn_interpolate_kernel(
         const vec_t a = *reinterpret_cast<const vec_t *>(pb + (size_t)s_i[r * 3] * c + col);
         const vec_t bb = *reinterpret_cast<const vec_t *>(pb + (size_t)s_i[r * 3 + 1] * c + col);
         const vec_t cc = *reinterpret_cast<const vec_t *>(pb + (size_t)s_i[r * 3 + 2] * c + col);
-        const vec_t v = a * s_w[r * 3] + bb * s_w[r * 3 + 1] + cc * s_w[r * 3 + 2];
-        *reinterpret_cast<vec_t *>(out + ((size_t)bi * n + j0 + r) * ldo + col) = v;
+        vec_t v = a * s_w[r * 3] + bb * s_w[r * 3 + 1] + cc * s_w[r * 3 + 2];
+        vec_t *op = reinterpret_cast<vec_t *>(out + ((size_t)bi * n + j0 + r) * ldo + col);
+        if (epi) {                                   // 1: out += v;  2: out = relu(out + v)
+            v = *op + v;
+            if (epi == 2) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) v[q] = fmaxf(v[q], 0.f);
+            }
+        }
+        *op = v;
     }
 }
 
@@ -269,9 +277,9 @@ extern "C" int prcnn_three_interpolate(int b, int m, int c, int n, const float *
     return PRCNN_OK;
 }
 
-extern "C" int prcnn_three_nn_interpolate(int b, int n, int m, int c, const float *xyz1,
-                                          const float *xyz2, const float *points2, float *out,
-                                          int64_t ldo, float *dist, int *idx, prcnn_stream_t stream)
+static int launch_fused_nn(int b, int n, int m, int c, const float *xyz1, const float *xyz2,
+                           const float *points2, float *out, int64_t ldo, float *dist, int *idx, int epi,
+                           prcnn_stream_t stream)
 {
     using namespace prcnn;
     if (b < 0 || n < 0 || m <= 0 || c <= 0 || ldo < c) return PRCNN_BAD_SHAPE;
@@ -283,10 +291,34 @@ extern "C" int prcnn_three_nn_interpolate(int b, int n, int m, int c, const floa
     const bool a16 = (((uintptr_t)points2 | (uintptr_t)out) & 15) == 0 && ldo % 4 == 0;
     if (c % 4 == 0 && a16)
         hipLaunchKernelGGL(three_nn_interpolate_kernel<4>, grid, dim3(FU_THREADS), 0, st, n, m, c, xyz1,
-                           xyz2, points2, out, (long long)ldo, dist, idx);
+                           xyz2, points2, out, (long long)ldo, dist, idx, epi);
     else
         hipLaunchKernelGGL(three_nn_interpolate_kernel<1>, grid, dim3(FU_THREADS), 0, st, n, m, c, xyz1,
-                           xyz2, points2, out, (long long)ldo, dist, idx);
+                           xyz2, points2, out, (long long)ldo, dist, idx, epi);
     PRCNN_LAUNCH_CHECK();
     return PRCNN_OK;
+}
+
+extern "C" int prcnn_three_nn_interpolate(int b, int n, int m, int c, const float *xyz1,
+                                          const float *xyz2, const float *points2, float *out,
+                                          int64_t ldo, float *dist, int *idx, prcnn_stream_t stream)
+{
+    return launch_fused_nn(b, n, m, c, xyz1, xyz2, points2, out, ldo, dist, idx, 0, stream);
+}
+
+// declared in nn_sorted.hip
+int prcnn_ns_fused(int b, int n, int m, int c, const float *xyz1, const float *xyz2, const float *points2,
+                   float *out, int64_t ldo, float *dist, int *idx, int epi, void *ws, size_t ws_bytes,
+                   prcnn_stream_t stream);
+
+extern "C" int prcnn_three_nn_interpolate_add(int b, int n, int m, int c, const float *xyz1,
+                                              const float *xyz2, const float *points2, float *out,
+                                              int64_t ldo, int relu, void *workspace,
+                                              size_t workspace_bytes, prcnn_stream_t stream)
+{
+    const int epi = relu ? 2 : 1;
+    if (workspace)
+        return prcnn_ns_fused(b, n, m, c, xyz1, xyz2, points2, out, ldo, nullptr, nullptr, epi, workspace,
+                              workspace_bytes, stream);
+    return launch_fused_nn(b, n, m, c, xyz1, xyz2, points2, out, ldo, nullptr, nullptr, epi, stream);
 }

@@ -327,6 +327,32 @@ def three_nn_interpolate(xyz1, xyz2, points2, out=None, return_nn=False):
     return (out, dist, idx) if return_nn else out
 
 
+def three_nn_interpolate_add(xyz1, xyz2, points2, out, relu=True):
+    """out[..., :c] = act(out[..., :c] + interpolate(points2)) in place: epilogue of the split
+    FP layer (see prcnn_three_nn_interpolate_add)."""
+    xyz1 = _dev(xyz1, torch.float32, "three_nn_interpolate_add xyz1", 3, 3)
+    xyz2 = _dev(xyz2, torch.float32, "three_nn_interpolate_add xyz2", 3, 3)
+    points2 = _dev(points2, torch.float32, "three_nn_interpolate_add points2", 3)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    c = points2.shape[2]
+    if xyz2.shape[0] != b or points2.shape[0] != b or points2.shape[1] != m:
+        raise ValueError("three_nn_interpolate_add expects xyz2 (b,m,3) and points2 (b,m,c)")
+    if (not isinstance(out, torch.Tensor) or not out.is_cuda or out.dtype != torch.float32
+            or not out.is_contiguous() or out.dim() != 3 or out.shape[:2] != (b, n) or out.shape[2] < c):
+        raise ValueError("three_nn_interpolate_add: out must be a contiguous (b,n,>=c) float32 GPU tensor")
+    L = _lib.lib()
+    ws, nb = None, 0
+    if _use_sorted_nn(n, m):
+        nb = L.prcnn_three_nn_sorted_workspace_bytes(b, n, m)
+        ws = torch.empty((nb,), dtype=torch.uint8, device=xyz1.device)
+    _lib.check(_run("three_nn_interpolate", {"tests": b * n * m, "bytes": b * (12 * n + 12 * m) + b * n * 20 * c},
+                    lambda: L.prcnn_three_nn_interpolate_add(b, n, m, c, _p(xyz1), _p(xyz2), _p(points2), _p(out),
+                                                             out.shape[2], 1 if relu else 0, _p(ws), nb, _stream())),
+               "three_nn_interpolate_add")
+    return out
+
+
 # ---- shared MLP -------------------------------------------------------------------------
 
 def mlp_layer(x, w, scale, shift, relu=True, pool=1, precision=PRECISION_FP32, out=None, out_col=0):

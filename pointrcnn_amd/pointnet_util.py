@@ -38,6 +38,12 @@ class ParamStore(dict):
         self.device = device
         self.randomize_bn = randomize_bn
 
+    def zeros(self, n):
+        key = '__zeros_%d' % n
+        if key not in self:
+            self[key] = torch.zeros(n, dtype=torch.float32, device=self.device)
+        return self[key]
+
     def layer(self, name, cin, cout, bn=True):
         if name not in self:
             lim = math.sqrt(6.0 / (cin + cout))                     # xavier_initializer
@@ -56,6 +62,9 @@ class ParamStore(dict):
         if W.shape != (cin, cout):
             raise ValueError("%s: stored weight %s does not match (%d,%d)" % (name, tuple(W.shape), cin, cout))
         return W, s, t
+
+
+FP_SPLIT = True      # split the first FP convolution around the interpolation (pointnet_fp_module)
 
 
 def fold_bn(W, bias, gamma, beta, mean, var, eps=1e-3, bn=True, device="cuda"):
@@ -254,6 +263,29 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
     precision = PRECISION if precision is None else precision
     b, n, _ = xyz1.shape
     c2 = points2.shape[2]
+    if FUSED and FP_SPLIT and len(mlp) >= 1:
+        # The interpolation is linear, so the wide half of the first convolution runs on the m
+        # known rows instead of the n (= 4m) interpolated rows:
+        #   relu(s*([interp, p1] W) + t) = relu(interp3((p2 W_a) s) + (p1 W_b) s + t)
+        # (concat order [interpolated, points1]: pointnet_util.py:218).  Same value up to fp32
+        # re-association (tolerance tier, like every MLP output); FP_SPLIT = False keeps the
+        # concat form.
+        m = xyz2.shape[1]
+        c1 = 0 if points1 is None else points1.shape[2]
+        co = mlp[0]
+        W, s, t = store.layer('%s/conv_0' % scope, c2 + c1, co, bn)
+        y2 = ops.mlp_layer(points2.reshape(b * m, c2), W[:c2], s, store.zeros(co), relu=False, precision=precision)
+        if points1 is not None:
+            x = ops.mlp_layer(points1.reshape(b * n, c1), W[c2:], s, t, relu=False, precision=precision)
+        else:
+            x = t.expand(b * n, co).contiguous()
+        ops.three_nn_interpolate_add(xyz1, xyz2, y2.reshape(b, m, co), x.reshape(b, n, co), relu=True)
+        c = co
+        for i, co in enumerate(mlp[1:], 1):
+            W, s, t = store.layer('%s/conv_%d' % (scope, i), c, co, bn)
+            x = ops.mlp_layer(x, W, s, t, relu=True, precision=precision)
+            c = co
+        return x.reshape(b, n, mlp[-1])
     if FUSED:
         c1 = 0 if points1 is None else points1.shape[2]
         new_points1 = torch.empty((b, n, c2 + c1), dtype=torch.float32, device=xyz1.device)

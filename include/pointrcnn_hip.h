@@ -228,6 +228,13 @@ int prcnn_three_nn_interpolate_add(int b, int n, int m, int c, const float *xyz1
                                    int64_t ldo, int relu, void *workspace, size_t workspace_bytes,
                                    prcnn_stream_t stream);
 
+/* out[:, :c] = out[:, :c] + three_interpolate(points, idx, weight) (then ReLU if relu != 0),
+ * rows of out at out + r*ldo: the element-parallel form of the epilogue above, for levels
+ * whose search is small (idx / weight from prcnn_three_nn + prcnn_fp_weights). */
+int prcnn_three_interpolate_add(int b, int m, int c, int n, const float *points, const int *idx,
+                                const float *weight, float *out, int64_t ldo, int relu,
+                                prcnn_stream_t stream);
+
 /* prcnn_query_ball_point_msg with the spatially culled search (additive; identical idx /
  * pts_cnt): points are bucketed and tiled, a wave of four neighbouring centroids visits only
  * tiles within the largest radius, and the per-ball hits are reduced to the nsample smallest

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(int m, int c, in
                                                                 const float *__restrict__ points,
                                                                 const int *__restrict__ idx,
                                                                 const float *__restrict__ weight,
-                                                                float *__restrict__ out)
+                                                                float *__restrict__ out, long long ldo, int epi)
 {
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
     const int cv = c / VEC;
@@ -151,8 +151,16 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(int m, int c, in
         const vec_t a = *reinterpret_cast<const vec_t *>(pb + (size_t)i1 * c);
         const vec_t bb = *reinterpret_cast<const vec_t *>(pb + (size_t)i2 * c);
         const vec_t cc = *reinterpret_cast<const vec_t *>(pb + (size_t)i3 * c);
-        const vec_t r = a * w1 + bb * w2 + cc * w3;   // unfused: -ffp-contract=off
-        *reinterpret_cast<vec_t *>(out + (size_t)row * c + col) = r;
+        vec_t r = a * w1 + bb * w2 + cc * w3;         // unfused: -ffp-contract=off
+        vec_t *op = reinterpret_cast<vec_t *>(out + (size_t)row * ldo + col);
+        if (epi) {                                    // 1: out += r;  2: out = relu(out + r)
+            r = *op + r;
+            if (epi == 2) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) r[q] = fmaxf(r[q], 0.f);
+            }
+        }
+        *op = r;
     }
 }
 
@@ -249,32 +257,45 @@ extern "C" int prcnn_fp_weights(int64_t rows, const float *dist, float *weight,
     return PRCNN_OK;
 }
 
-extern "C" int prcnn_three_interpolate(int b, int m, int c, int n, const float *points,
-                                       const int *idx, const float *weight, float *out,
-                                       prcnn_stream_t stream)
+static int launch_interpolate(int b, int m, int c, int n, const float *points, const int *idx,
+                              const float *weight, float *out, int64_t ldo, int epi, prcnn_stream_t stream)
 {
     using namespace prcnn;
-    if (b < 0 || m <= 0 || c < 0 || n < 0) return PRCNN_BAD_SHAPE;   // tf_interpolate.cpp:203,206
+    if (b < 0 || m <= 0 || c < 0 || n < 0 || ldo < c) return PRCNN_BAD_SHAPE;   // tf_interpolate.cpp:203,206
     const long long rows = (long long)b * n;
     if (rows == 0 || c == 0) return PRCNN_OK;
     if (!points || !idx || !weight || !out) return PRCNN_BAD_SHAPE;
     hipStream_t st = to_stream(stream);
-    const bool a16 = (((uintptr_t)points | (uintptr_t)out) & 15) == 0;
+    const bool a16 = (((uintptr_t)points | (uintptr_t)out) & 15) == 0 && ldo % 4 == 0;
     if (c % 4 == 0 && a16) {
         const long long tv = rows * (c / 4);
         long long blocks = (tv + 255) / 256;
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(three_interpolate_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, m, c,
-                           n, tv, points, idx, weight, out);
+                           n, tv, points, idx, weight, out, (long long)ldo, epi);
     } else {
         const long long tv = rows * c;
         long long blocks = (tv + 255) / 256;
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(three_interpolate_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, m, c,
-                           n, tv, points, idx, weight, out);
+                           n, tv, points, idx, weight, out, (long long)ldo, epi);
     }
     PRCNN_LAUNCH_CHECK();
     return PRCNN_OK;
+}
+
+extern "C" int prcnn_three_interpolate(int b, int m, int c, int n, const float *points,
+                                       const int *idx, const float *weight, float *out,
+                                       prcnn_stream_t stream)
+{
+    return launch_interpolate(b, m, c, n, points, idx, weight, out, c, 0, stream);
+}
+
+extern "C" int prcnn_three_interpolate_add(int b, int m, int c, int n, const float *points,
+                                           const int *idx, const float *weight, float *out,
+                                           int64_t ldo, int relu, prcnn_stream_t stream)
+{
+    return launch_interpolate(b, m, c, n, points, idx, weight, out, ldo, relu ? 2 : 1, stream);
 }
 
 static int launch_fused_nn(int b, int n, int m, int c, const float *xyz1, const float *xyz2,

@@ -327,6 +327,12 @@ def three_nn_interpolate(xyz1, xyz2, points2, out=None, return_nn=False):
     return (out, dist, idx) if return_nn else out
 
 
+# Up to this many queries (b*n) three_nn_interpolate_add runs search and interpolation as
+# separate launches.  Measured (b16, fused -> two-step): n256 C512: 61 -> 31 us; n1024 C512:
+# 118 -> 48 us; n4096 C256: 119 -> 110 us; n16384 C128: 203 -> 238 us (stays fused).
+FP_TWO_STEP_MAX_QUERIES = 65536
+
+
 def three_nn_interpolate_add(xyz1, xyz2, points2, out, relu=True):
     """out[..., :c] = act(out[..., :c] + interpolate(points2)) in place: epilogue of the split
     FP layer (see prcnn_three_nn_interpolate_add)."""
@@ -342,6 +348,16 @@ def three_nn_interpolate_add(xyz1, xyz2, points2, out, relu=True):
             or not out.is_contiguous() or out.dim() != 3 or out.shape[:2] != (b, n) or out.shape[2] < c):
         raise ValueError("three_nn_interpolate_add: out must be a contiguous (b,n,>=c) float32 GPU tensor")
     L = _lib.lib()
+    if FP_TWO_STEP_MAX_QUERIES is not None and b * n <= FP_TWO_STEP_MAX_QUERIES:
+        # few queries: the fused kernel's interpolation phase (one workgroup per 256 queries)
+        # cannot fill the chip; search, then an element-parallel interpolation
+        dist, idx = three_nn(xyz1, xyz2)
+        weight = fp_weights(dist)
+        _lib.check(_run("three_interpolate", {"bytes": b * n * (24 + 20 * c)},
+                        lambda: L.prcnn_three_interpolate_add(b, m, c, n, _p(points2), _p(idx), _p(weight), _p(out),
+                                                              out.shape[2], 1 if relu else 0, _stream())),
+                   "three_interpolate_add")
+        return out
     ws, nb = None, 0
     if _use_sorted_nn(n, m):
         nb = L.prcnn_three_nn_sorted_workspace_bytes(b, n, m)

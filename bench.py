@@ -11,11 +11,14 @@ matrix cores, followed by the rotated BEV NMS of each scene's 2048 proposals (to
 IoU 0.8: the reference's val/test setting) and -- for N>1 -- ONE all-gather of the
 per-scene detection records.  One "step" = one such batch per rank (weak scaling: every
 rank processes its own 16 scenes per step).  Inputs are resident in HBM before the timed
-region.  Each step is one HIP-graph replay; steps alternate over two streams, and inside a
-step the strictly serial, 16-CU farthest-point-sampling chain of the NEXT batch of that
-stream runs beside the full-chip feature phase of the current batch (software pipelining
-by one batch: every step still executes exactly one FPS chain and one feature phase, see
-pipelined_step; --no-pipeline samples inside the batch's own step).
+region.  Steps are issued as HIP-graph replays of `--fps-group` (default 4) batches each,
+alternating over two streams (a remainder of K mod 4 steps runs as single-batch replays, so
+exactly K steps are timed).  Inside a replay the strictly serial farthest-point-sampling
+chain runs ONCE over the clouds of that stream's NEXT four batches (64 workgroups, 6.3 ms
+whatever the number of clouds) beside the full-chip feature phases of the current four
+(software pipelining: every batch still gets one complete FPS pass and one complete feature
+phase, see pipelined_step; --no-pipeline samples inside the batch's own step, --fps-group 1
+pipelines batch by batch).
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant roofline-bound
 kernel, durations measured with HIP events inside the timed region), `kernels` (every
@@ -71,22 +74,29 @@ def step(pcs, prop, store, precision, geo=None, centroids=None):
     return feats, rec
 
 
-def pipelined_step(pcs_cur, pcs_next, prop, store, precision, cent_cur, cent_next, side):
-    """One step of the software-pipelined schedule: the feature phase of the current batch
-    (grouping, MLPs, interpolation, NMS, records) runs on the current stream with the
-    centroids sampled one step earlier, while the strictly serial FPS chain of the NEXT
-    batch runs on `side` into `cent_next`.  Every step still executes one complete FPS
-    chain and one complete feature phase; only their pairing is shifted by one batch, so the
-    16-CU, latency-bound sampling never gates the full-chip work of its own batch."""
+def pipelined_step(pcs_cur, pcs_next, prop, store, precision, cent_cur, cent_next, side, group=1):
+    """`group` steps of the software-pipelined schedule: the feature phases of the current
+    `group` batches (grouping, MLPs, interpolation, NMS, records) run one after the other on
+    the current stream with the centroids sampled one replay earlier, while ONE strictly
+    serial FPS chain over the clouds of the NEXT `group` batches (group x 16 workgroups) runs
+    on `side` into `cent_next`.  Every batch still gets one complete FPS pass and one complete
+    feature phase; only their pairing is shifted, so the latency-bound sampling (6.3 ms per
+    chain whatever the number of clouds, 16 CUs per batch) never gates full-chip work, and
+    one chain's latency is spread over `group` batches.  Returns one (feats, rec) per batch."""
     cur = torch.cuda.current_stream()
     side.wait_stream(cur)
     with torch.cuda.stream(side):
-        xs, _ = stacks.sample_centroid_chain(pcs_next[:, :, 0:3].contiguous(), [lv[0] for lv in stacks.RPN_SA])
+        xyz_next = pcs_next[:, :, 0:3].contiguous()
+        if group > 1:
+            xyz_next = xyz_next.repeat(group, 1, 1)          # synthetic input: the same batch again
+        xs, _ = stacks.sample_centroid_chain(xyz_next, [lv[0] for lv in stacks.RPN_SA])
         for dst, x in zip(cent_next, xs):
             dst.copy_(x)
-    out = step(pcs_cur, prop, store, precision, centroids=cent_cur)
+    b = pcs_cur.shape[0]
+    outs = [step(pcs_cur, prop, store, precision, centroids=[c[g * b:(g + 1) * b] for c in cent_cur])
+            for g in range(group)]
     cur.wait_stream(side)
-    return out
+    return outs
 
 
 def time_nms(device, n=9000, iters=20):
@@ -159,8 +169,8 @@ def cpu_baseline(store, seconds_cap=40.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32")
     # concurrent batches in flight; each has a companion stream for the next batch's FPS chain,
     # and 2+2 streams = HIP's 4 hardware queues (measured: 3+3 aliases queues and loses 20 %)
@@ -170,6 +180,8 @@ def main():
     ap.add_argument("--geo-stream", action="store_true",
                     help="run each step's FPS chain on a companion stream (helps only single-batch latency)")
     ap.add_argument("--no-graph", action="store_true", help="issue every step eagerly instead of replaying HIP graphs")
+    ap.add_argument("--fps-group", type=int, default=4,
+                    help="batches per graph replay: one FPS chain samples this many upcoming batches at once")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="sample each batch's centroids inside its own step instead of one step ahead")
     args = ap.parse_args()
@@ -190,23 +202,30 @@ def main():
     # synchronises, so it captures as is); the all-gather stays outside the graph.
     graphs, outs = [], []
     pipelined = not (args.no_graph or args.no_pipeline or args.geo_stream)
+    group = max(1, args.fps_group) if pipelined else 1
     if pipelined:
-        # two graphs per stream (ping-pong over two centroid sets): replay r reads set r%2,
-        # which replay r-1 of the same stream filled, and fills set (r+1)%2
+        # two graphs per stream and unit size (ping-pong over two centroid sets): replay r reads
+        # set r%2, which replay r-1 of the same kind on the same stream filled, and fills set
+        # (r+1)%2.  Units of `group` batches carry the bulk; single-batch units serve the
+        # remainder when the step count is not a multiple of `group`.
         sides = [torch.cuda.Stream(device=device) for _ in streams]
         for st, side in zip(streams, sides):
-            with torch.cuda.stream(st):
-                xs, _ = stacks.sample_centroid_chain(pcs[:, :, 0:3].contiguous(), [lv[0] for lv in stacks.RPN_SA])
-                cents = [[x.clone() for x in xs], [x.clone() for x in xs]]
-                pipelined_step(pcs, pcs, prop, store, precision, cents[0], cents[1], side)   # warm-up
-            torch.cuda.synchronize()
-            pair, opair = [], []
-            for w in (0, 1):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=st):
-                    o = pipelined_step(pcs, pcs, prop, store, precision, cents[w], cents[1 - w], side)
-                pair.append(g); opair.append(o)
-            graphs.append(pair); outs.append(opair)
+            kinds = {}
+            for G in sorted({group, 1}):
+                with torch.cuda.stream(st):
+                    xs, _ = stacks.sample_centroid_chain(pcs[:, :, 0:3].contiguous().repeat(G, 1, 1),
+                                                         [lv[0] for lv in stacks.RPN_SA])
+                    cents = [[x.clone() for x in xs], [x.clone() for x in xs]]
+                    pipelined_step(pcs, pcs, prop, store, precision, cents[0], cents[1], side, G)   # warm-up
+                torch.cuda.synchronize()
+                pair, opair = [], []
+                for w in (0, 1):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=st):
+                        o = pipelined_step(pcs, pcs, prop, store, precision, cents[w], cents[1 - w], side, G)
+                    pair.append(g); opair.append(o)
+                kinds[G] = (pair, opair)
+            graphs.append(kinds); outs.append(None)
     elif not args.no_graph:
         for st, geo in zip(streams, geos):
             with torch.cuda.stream(st):
@@ -217,20 +236,27 @@ def main():
                 o = step(pcs, prop, store, precision, geo)
             graphs.append(g); outs.append(o)
 
-    replays = [0] * len(streams)
+    replays = [{group: 0, 1: 0} for _ in streams]
 
     def run_steps(k, timer=None):
         prev = ops.set_timer(timer)
         try:
+            if graphs and timer is None and pipelined:
+                units = [group] * (k // group) + [1] * (k % group)
+                for u, G in enumerate(units):
+                    j = u % len(streams)
+                    with torch.cuda.stream(streams[j]):
+                        w = replays[j][G] & 1
+                        replays[j][G] += 1
+                        pair, opair = graphs[j][G]
+                        pair[w].replay()
+                        for _, rec in opair[w]:
+                            pdist.all_gather_detections(rec)
+                return
             for i in range(k):
                 j = i % len(streams)
                 with torch.cuda.stream(streams[j]):
-                    if graphs and timer is None and pipelined:
-                        w = replays[j] & 1
-                        replays[j] += 1
-                        graphs[j][w].replay()
-                        rec = outs[j][w][1]
-                    elif graphs and timer is None:
+                    if graphs and timer is None:
                         graphs[j].replay()
                         rec = outs[j][1]
                     else:
@@ -341,7 +367,7 @@ def main():
                                    (args.batch, NPTS, NPROP, " + RCCL all-gather of detections" if world > 1 else ""),
                        "batch_per_gpu": args.batch, "points": NPTS, "streams": len(streams),
                        "hip_graph": bool(graphs), "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3),
-                       "geometry_streams": bool(args.geo_stream), "fps_one_step_ahead": bool(pipelined),
+                       "geometry_streams": bool(args.geo_stream), "fps_one_step_ahead": bool(pipelined), "batches_per_replay": group,
                        "kernel_timing": "HIP events around every launch in an eager, single-stream instrumented "
                                         "pass of the same steps after the timed region",
                        "parallelism": "scene-sharded x%d" % world},

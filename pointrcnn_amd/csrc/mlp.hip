@@ -113,7 +113,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
 // ---- kernel ---------------------------------------------------------------------------
 // WM x WN waves (WM*WN == 4), each wave owns TM x TN MFMA tiles of 32x32.
 template <int WM, int WN, int TM, int TN, bool GATHER, bool BF16, int KB>
-__global__ __launch_bounds__(MLP_THREADS) void mlp_kernel(const MlpArgs a)
+__global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void mlp_kernel(const MlpArgs a)
 {
     constexpr int BN = WN * TN * 32;
     constexpr int BK = BF16 ? 32 : KB;             // fp32: 16 (narrow inputs) or 32

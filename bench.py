@@ -113,6 +113,22 @@ def time_nms(device, n=9000, iters=20):
     return e0.elapsed_time(e1) / iters, int(nk.item())
 
 
+def time_hbm_copy(device, mbytes=1024, iters=10):
+    """Device-to-device copy rate (read + write bytes / time): the practical HBM figure on this
+    box next to the 8 TB/s used as `peak`."""
+    a = torch.empty(mbytes << 20, dtype=torch.uint8, device=device)
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * (mbytes << 20) * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def time_fps_dense(device, n=131072, m=16384):
     """BASELINE config 5, second half: FPS on a 131072-point dense scene."""
     pts = torch.as_tensor(S.dense_scene(5000, n)[None, :, :3].copy()).to(device)
@@ -334,6 +350,7 @@ def main():
             pmc_keys = {   # (kernel family, shape) -> entry of the PMC summary (tools/pmc_probe.py launches these shapes)
                 ("mlp_layer", "rows65536 K608 N256 pool1"): "mlp_kernel<2, 2, 2, 2, false, false, 16> grid_threads=262144",
                 ("mlp_layer", "rows262144 K260 N128 pool1"): "mlp_kernel<2, 2, 2, 2, false, false, 16> grid_threads=524288",
+                ("mlp_layer", "rows524288 K96 N128 pool32"): "mlp_kernel<2, 2, 2, 2, false, false, 16> grid_threads=1048576",
                 ("sa_chain", "rows2097152 K4 N32-32-64 pool32"): "sa_chain_kernel<4, 32, 32, 64>",
             }
             pk = pmc_keys.get((best["kernel"], best["shape"]))
@@ -357,6 +374,7 @@ def main():
                    "ms_total": round(d["ms"], 3), "launches": d["launches"],
                    "gdist_evals_per_s": round(d["dist_evals"] / (d["ms"] * 1e-3) / 1e9, 2)}
         nms_ms, nms_keep = time_nms(device)
+        hbm_copy = time_hbm_copy(device)
         out = {
             "metric": "SA/FP-stack scenes/sec (16k pts)", "value": round(scenes / elapsed, 2), "unit": "scenes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -375,6 +393,7 @@ def main():
             "nms": {"ms_9000_to_100": round(nms_ms, 4), "kept": nms_keep, "pairs": 9000 * 8999 // 2,
                     "metric": "rotated-NMS ms @9k boxes"},
             "fps_dense": time_fps_dense(device),
+            "hbm_copy_gbps": {"value": round(hbm_copy, 1), "what": "torch device-to-device copy of 1 GiB, read+write bytes / time"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(store)

@@ -377,7 +377,8 @@ static int launch_mlp(const MlpArgs &a, hipStream_t st)
     if (rb > 0x7fffffffLL) return PRCNN_UNSUPPORTED;
     // tile width: as wide as cout allows, but narrower when the grid would leave most of
     // the 256 CUs (x3 resident workgroups) without work
-    // Tile width, from the batch-16 sweep in profiles/r01_mlp_tile_sweep.txt: 128 columns
+    // Tile width, from the batch-16 sweeps in profiles/r01_mlp_tile_sweep.txt (3 waves/SIMD build)
+    // and r01_mlp_tile_sweep2.txt (current 4 waves/SIMD build): 128 columns
     // amortise the A staging best when K is large or the grid is many rounds deep; 64 columns
     // (4 waves/SIMD instead of 3, twice the workgroups) win on shallow grids; never pad a
     // narrow layer up to a wide tile.
@@ -387,9 +388,7 @@ static int launch_mlp(const MlpArgs &a, hipStream_t st)
     else if (a.cout <= 64) bn = 64;
     else if (a.cout <= 96) bn = rb >= 2048 ? 32 : 64;
     else if (wgs128 < 256) bn = rb * ((a.cout + 63) / 64) < 256 ? 32 : 64;
-    else if (a.cin >= 512) bn = 128;
-    else if (wgs128 <= 1024) bn = 64;
-    else bn = 128;
+    else bn = 128;      // at 4 waves/SIMD the 128-wide tile wins from one workgroup per CU on (sweep 2)
     if (const char *f = getenv("PRCNN_MLP_BN")) bn = atoi(f);   // tuning aid (32 / 64 / 128)
     // measured (profiles/r01_mlp_tile_sweep.txt): 32-deep fp32 chunks do not pay (the kernel is
     // MFMA-issue bound, not barrier bound), so fp32 stays at 16

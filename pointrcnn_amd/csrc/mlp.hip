@@ -121,7 +121,11 @@ __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     constexpr int AS = BF16 ? 20 : BK + 4;          // both conflict-free for ds_read_b128
     constexpr int A_WORDS = BM * AS;
     // B: fp32 [BK][BN] words; bf16 transposed [BN][BK] bf16 = [BN][16 words] -> stride 20
-    constexpr int B_WORDS = BF16 ? BN * AS : BK * BN;
+    // fp32 B rows are padded by 4 words: the two lane-halves of a fragment read rows 8 apart, and
+    // 8*(BN+4) = 32 (mod 64) puts them on different bank halves (8*BN = 0 collided: one conflict
+    // cycle per MFMA in profiles/r01_pmc_lds_counters.json)
+    constexpr int BS = BN + 4;
+    constexpr int B_WORDS = BF16 ? BN * AS : BK * BS;
     constexpr int POOL_WORDS = (BM / 16) * BN;
     constexpr int LDS_WORDS = (A_WORDS + B_WORDS) > POOL_WORDS ? (A_WORDS + B_WORDS) : POOL_WORDS;
     __shared__ __attribute__((aligned(16))) unsigned lds[LDS_WORDS];
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
                 *reinterpret_cast<f32x4 *>(&As[arow * AS + ahalf * A_PER + v * 4]) = areg[v];
 #pragma unroll
             for (int e = 0; e < B_PER; ++e)
-                Bs[bk * BN + bn + e] = __builtin_bit_cast(unsigned, breg[e]);
+                Bs[bk * BS + bn + e] = __builtin_bit_cast(unsigned, breg[e]);
         } else {
             // A: 16 bf16 per thread = 8 words at As[arow][ahalf*8 ..]
 #pragma unroll
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
                 float bf[TN];
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    bf[j] = __builtin_bit_cast(float, Bs[(kh * KS + s) * BN + (wn * TN + j) * 32 + li]);
+                    bf[j] = __builtin_bit_cast(float, Bs[(kh * KS + s) * BS + (wn * TN + j) * 32 + li]);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll

@@ -344,14 +344,20 @@ static size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 static NsWs ns_carve(void *ws, long long b, long long n, long long m)
 {
     const long long tiles = (m + 63) / 64;
-    char *p = reinterpret_cast<char *>(ws);
     size_t o = 0;
-    NsWs w;
-    w.list_q = reinterpret_cast<int *>(p + o); o += up256((size_t)b * n * 4);
-    w.list_k = reinterpret_cast<int *>(p + o); o += up256((size_t)b * m * 4);
-    w.kp = reinterpret_cast<float4 *>(p + o); o += up256((size_t)b * tiles * 64 * 16);
-    w.tb = reinterpret_cast<float *>(p + o); o += up256((size_t)b * tiles * 8 * 4);
+    const size_t o_q = o; o += up256((size_t)b * n * 4);
+    const size_t o_k = o; o += up256((size_t)b * m * 4);
+    const size_t o_p = o; o += up256((size_t)b * tiles * 64 * 16);
+    const size_t o_t = o; o += up256((size_t)b * tiles * 8 * 4);
+    NsWs w = {};
     w.bytes = o;
+    if (ws) {                                   // sizes only when called without a buffer
+        char *p = reinterpret_cast<char *>(ws);
+        w.list_q = reinterpret_cast<int *>(p + o_q);
+        w.list_k = reinterpret_cast<int *>(p + o_k);
+        w.kp = reinterpret_cast<float4 *>(p + o_p);
+        w.tb = reinterpret_cast<float *>(p + o_t);
+    }
     return w;
 }
 

@@ -267,8 +267,9 @@ def main():
                         replays[j][G] += 1
                         pair, opair = graphs[j][G]
                         pair[w].replay()
-                        for _, rec in opair[w]:
-                            pdist.all_gather_detections(rec)
+                        # one collective per replay: the records of its batches travel together
+                        recs = [rec for _, rec in opair[w]]
+                        pdist.all_gather_detections(recs[0] if len(recs) == 1 or world == 1 else torch.cat(recs, 0))
                 return
             for i in range(k):
                 j = i % len(streams)

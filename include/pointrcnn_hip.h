@@ -298,6 +298,34 @@ int prcnn_selection_sort(int b, int n, int m, int k, const float *dist, int *out
 int prcnn_knn_point(int b, int n, int m, int k, const float *xyz1, const float *xyz2, float *val,
                     int *idx, prcnn_stream_t stream);
 
+/* ---- RPN proposal post-processing (TensorFlow graph ops in the
+ * reference, no native kernel) ----------------------------------------------------------------
+ * BoxEncoder.tf_decode (utils/box_encoder.py:109-179) + "box_center + fg_points_xyz"
+ * (models/rpn.py:109) + get_box3d_corners_helper (models/model_util.py:55-82) + the confidence
+ * product and BEV boxes of RPN.reduce_proposals (models/rpn.py:213-227), one pass per proposal.
+ * head_output (b,n,4*NCB+1+2*NHB+4*NSC) laid out as models/rpn.py:76-104; fg_logits (b,n,2) or
+ * NULL (segmentation score 1); host_mean_sizes NSC x (l,h,w).  Any output may be NULL.
+ * center (b,n,3), angle (b,n), size (b,n,3), corners (b,n,8,3), confidence (b,n),
+ * bev_boxes (b,n,4) = [min x, min z, max x, max z]. */
+int prcnn_rpn_decode_proposals(int b, int n, int num_center_bin, int num_heading_bin,
+                               int num_size_cluster, float center_search_range,
+                               float heading_search_range, const float *host_mean_sizes,
+                               const float *head_output, const float *fg_points_xyz,
+                               const float *fg_logits, float *center, float *angle, float *size,
+                               float *corners, float *confidence, float *bev_boxes,
+                               prcnn_stream_t stream);
+
+/* tf.image.non_max_suppression(boxes, scores, max_output_size, iou_threshold) per frame
+ * (models/rpn.py:236; TensorFlow NonMaxSuppression semantics: decreasing score, drop when IoU
+ * with a selected box is > iou_threshold, (y1,x1,y2,x2) in any corner order, boxes of
+ * non-positive area neither suppress nor are suppressed).  boxes (batch,n,4) f32, scores
+ * (batch,n) f64 (exact widening of the f32 scores), keep (batch,max_output_size) int64,
+ * n_keep (batch).  Equal scores: lower index first (TensorFlow's heap order is unspecified).
+ * workspace: prcnn_nms_rotate_batched_workspace_bytes(batch, n). */
+int prcnn_nms_aabb_batched(int batch, int n, const float *boxes, const double *scores,
+                           float iou_threshold, int max_output_size, int64_t *keep, int *n_keep,
+                           void *workspace, size_t workspace_bytes, prcnn_stream_t stream);
+
 /* ---- scene-sharded harness (no counterpart in the reference, which is
  * single-GPU) ---------------------------------------------------------------------------------
  * One float32 record per scene for the per-step all-gather:

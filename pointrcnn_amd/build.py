@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpointrcnn_hip.so")
-SOURCES = ["c_api.hip", "fps.hip", "grouping.hip", "interp.hip", "nms_rotate.hip", "mlp.hip", "sa_chain.hip", "grad.hip", "nn_sorted.hip", "detections.hip", "knn.hip"]
+SOURCES = ["c_api.hip", "fps.hip", "grouping.hip", "interp.hip", "nms_rotate.hip", "mlp.hip", "sa_chain.hip", "grad.hip", "nn_sorted.hip", "detections.hip", "knn.hip", "rpn_head.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
          "-Wall", "-Wno-unused-function"]
 # per-file extra flags (measured choices)

@@ -316,6 +316,121 @@ static NmsLayout nms_layout(int batch, int n)
     return L;
 }
 
+
+// ---- axis-aligned NMS with tf.image.non_max_suppression semantics (models/rpn.py:236) ----------
+// TensorFlow's NonMaxSuppression (third-party, un-vendored; TF 1.x core/kernels/
+// non_max_suppression_op.cc): candidates in decreasing score order; a candidate is dropped when
+// its IoU with an already selected box is > iou_threshold; boxes are (y1,x1,y2,x2) in any corner
+// order; a box of non-positive area never suppresses and is never suppressed; all in float.
+// Same rank / bitmask / sweep structure as the rotated NMS; the record is the normalised box.
+struct AabbRec { float ymin, xmin, ymax, xmax, area, pad0, pad1, pad2; };
+
+__global__ __launch_bounds__(RANK_THREADS) void aabb_finalize_kernel(int n, const float *__restrict__ boxes_all,
+                                                                     const int *__restrict__ rank_all,
+                                                                     int *__restrict__ order_all,
+                                                                     AabbRec *__restrict__ rec_all)
+{
+    const int i = blockIdx.x * RANK_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const size_t so = (size_t)blockIdx.z * n;
+    const int rank = rank_all[so + i];
+    order_all[so + rank] = i;
+    const float *b = boxes_all + (so + i) * 4;
+    AabbRec r;
+    r.ymin = fminf(b[0], b[2]); r.xmin = fminf(b[1], b[3]);
+    r.ymax = fmaxf(b[0], b[2]); r.xmax = fmaxf(b[1], b[3]);
+    r.area = (r.ymax - r.ymin) * (r.xmax - r.xmin);
+    r.pad0 = r.pad1 = r.pad2 = 0.f;
+    rec_all[so + rank] = r;
+}
+
+__global__ __launch_bounds__(64) void aabb_mask_kernel(int n, int words, float thr,
+                                                       const AabbRec *__restrict__ rec_all,
+                                                       unsigned long long *__restrict__ mask_all)
+{
+    const AabbRec *rec = rec_all + (size_t)blockIdx.z * n;
+    unsigned long long *mask = mask_all + (size_t)blockIdx.z * n * words;
+    __shared__ AabbRec colb[64];
+    int rb, cb;
+    {
+        const long long t = blockIdx.x;
+        int lo = 0, hi = words - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            const long long start = (long long)mid * words - (long long)mid * (mid - 1) / 2;
+            if (start <= t) lo = mid; else hi = mid - 1;
+        }
+        rb = lo;
+        cb = rb + (int)(t - ((long long)rb * words - (long long)rb * (rb - 1) / 2));
+    }
+    const int lane = threadIdx.x;
+    const int r = rb * 64 + lane;
+    if (cb * 64 + lane < n) colb[lane] = rec[cb * 64 + lane];
+    __syncthreads();
+    if (r >= n) return;
+    const AabbRec me = rec[r];
+    unsigned long long bits = 0ull;
+    const int cmax = min(64, n - cb * 64);
+    for (int k = 0; k < cmax; ++k) {
+        if (cb * 64 + k <= r) continue;
+        const AabbRec o = colb[k];
+        if (me.area <= 0.f || o.area <= 0.f) continue;
+        const float iy = fmaxf(fminf(me.ymax, o.ymax) - fmaxf(me.ymin, o.ymin), 0.f);
+        const float ix = fmaxf(fminf(me.xmax, o.xmax) - fmaxf(me.xmin, o.xmin), 0.f);
+        const float inter = iy * ix;
+        const float iou = inter / (me.area + o.area - inter);
+        if (iou > thr) bits |= 1ull << k;
+    }
+    mask[(size_t)r * words + cb] = bits;
+}
+
+}  // namespace prcnn
+
+extern "C" int prcnn_nms_aabb_batched(int batch, int n, const float *boxes, const double *scores,
+                                      float iou_threshold, int max_output_size, int64_t *keep, int *n_keep,
+                                      void *workspace, size_t workspace_bytes, prcnn_stream_t stream)
+{
+    using namespace prcnn;
+    if (n < 0 || batch < 0) return PRCNN_BAD_SHAPE;
+    if (batch == 0) return PRCNN_OK;
+    if (!n_keep) return PRCNN_BAD_SHAPE;
+    if (batch > 65535) return PRCNN_UNSUPPORTED;
+    hipStream_t st = to_stream(stream);
+    if (n == 0 || max_output_size <= 0) {
+        if (hipMemsetAsync(n_keep, 0, sizeof(int) * (size_t)batch, st) != hipSuccess) return PRCNN_HIP_ERROR;
+        return PRCNN_OK;
+    }
+    if (!boxes || !scores || !keep) return PRCNN_BAD_SHAPE;
+    const NmsLayout L = nms_layout(batch, n);
+    if (L.words > SWEEP_MAX_WORDS) return PRCNN_UNSUPPORTED;
+    if (!workspace || workspace_bytes < L.total) return PRCNN_WORKSPACE;
+    if (((uintptr_t)workspace & 255) != 0) return PRCNN_WORKSPACE;
+    char *ws = (char *)workspace;
+    int *rank = (int *)(ws + L.rank_off);
+    int *order = (int *)(ws + L.order_off);
+    AabbRec *rec = (AabbRec *)(ws + L.rec_off);          // 32-byte records in the 64-byte slots
+    unsigned long long *mask = (unsigned long long *)(ws + L.mask_off);
+    if (hipMemsetAsync(rank, 0, sizeof(int) * (size_t)batch * n, st) != hipSuccess) return PRCNN_HIP_ERROR;
+    const int iblocks = (n + RANK_THREADS - 1) / RANK_THREADS;
+    int slices = (1024 + iblocks * batch - 1) / (iblocks * batch);
+    const int max_slices = (n + 511) / 512;
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    const int slice = (((n + slices - 1) / slices) + 3) & ~3;
+    slices = (n + slice - 1) / slice;
+    hipLaunchKernelGGL(rank_kernel, dim3(iblocks, slices, batch), dim3(RANK_THREADS), 0, st, n, slice, scores, rank);
+    hipLaunchKernelGGL(aabb_finalize_kernel, dim3(iblocks, 1, batch), dim3(RANK_THREADS), 0, st, n, boxes, rank,
+                       order, rec);
+    const long long nblk = (long long)L.words * (L.words + 1) / 2;
+    hipLaunchKernelGGL(aabb_mask_kernel, dim3((unsigned)nblk, 1, batch), dim3(64), 0, st, n, L.words,
+                       iou_threshold, rec, mask);
+    hipLaunchKernelGGL(sweep_kernel, dim3(batch), dim3(64), 0, st, n, L.words, max_output_size, mask, order,
+                       (long long *)keep, n_keep);
+    PRCNN_LAUNCH_CHECK();
+    return PRCNN_OK;
+}
+
+namespace prcnn {
 }  // namespace prcnn
 
 extern "C" size_t prcnn_nms_rotate_batched_workspace_bytes(int batch, int n)

@@ -326,6 +326,18 @@ int prcnn_nms_aabb_batched(int batch, int n, const float *boxes, const double *s
                            float iou_threshold, int max_output_size, int64_t *keep, int *n_keep,
                            void *workspace, size_t workspace_bytes, prcnn_stream_t stream);
 
+/* nms_on_bev / group_overlaps (test/test_frustum.py:191-218, get_iou :185-189): per frame, in index
+ * order, the first remaining detection groups every later remaining detection whose rotated BEV
+ * IoU with it is >= iou_threshold (> 0); the member with the highest score (earliest of equals)
+ * is kept.  boxes (frames,n,5) f64 rows [x, z, l, w, ry] (obj.t[0], obj.t[2], obj.l, obj.w,
+ * obj.ry of compute_box_3d, kitti/kitti_util.py:322-339), scores (frames,n) f64, counts
+ * (frames) = detections present per frame (NULL: n).  group_id (frames,n): group of each
+ * detection (-1 past counts); keep (frames,n): kept detection of group g at [g], -1 past n_keep.
+ * workspace: prcnn_nms_rotate_batched_workspace_bytes(frames, n); n <= 65536. */
+int prcnn_bev_group_keep(int frames, int n, const int *counts, const double *boxes,
+                         const double *scores, double iou_threshold, int *group_id, int *keep,
+                         int *n_keep, void *workspace, size_t workspace_bytes, prcnn_stream_t stream);
+
 /* ---- scene-sharded harness (no counterpart in the reference, which is
  * single-GPU) ---------------------------------------------------------------------------------
  * One float32 record per scene for the per-step all-gather:

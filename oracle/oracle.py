@@ -37,6 +37,8 @@ def lib():
         _lib.oracle_rotated_intersection.restype = ctypes.c_double
         _lib.oracle_rotated_iou.restype = ctypes.c_double
         _lib.oracle_nms_rotate.restype = ctypes.c_int
+        _lib.oracle_bev_iou.restype = ctypes.c_double
+        _lib.oracle_bev_group_keep.restype = ctypes.c_int
     return _lib
 
 
@@ -197,6 +199,28 @@ def nms_rotate_cpu(boxes, scores, iou_threshold, max_output_size, order=None,
     if return_margin:
         return keep, margin.value
     return keep
+
+
+def bev_iou(d1, d2):
+    """get_iou of test/test_frustum.py:185-189 on rows [x, z, l, w, ry]."""
+    d1 = np.ascontiguousarray(d1, np.float64)
+    d2 = np.ascontiguousarray(d2, np.float64)
+    return lib().oracle_bev_iou(_p(d1), _p(d2))
+
+
+def nms_on_bev(det, scores, iou_threshold=0.1, return_margin=False):
+    """test/test_frustum.py:191-218 for one frame: det (n,5) rows [x, z, l, w, ry] ->
+    (group id per detection, kept detection per group)."""
+    det = np.ascontiguousarray(det, np.float64).reshape(-1, 5)
+    scores = np.ascontiguousarray(scores, np.float64)
+    n = det.shape[0]
+    group = np.empty(max(n, 1), np.int32)
+    keep = np.empty(max(n, 1), np.int32)
+    margin = ctypes.c_double(0)
+    ng = lib().oracle_bev_group_keep(n, _p(det), _p(scores), ctypes.c_double(iou_threshold), _p(group), _p(keep),
+                                     ctypes.byref(margin))
+    out = (group[:n].copy(), keep[:ng].copy())
+    return out + (margin.value,) if return_margin else out
 
 
 def mlp_layer(x, w, scale, shift, relu=True):

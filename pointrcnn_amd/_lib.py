@@ -53,6 +53,7 @@ SIGNATURES = {
     "prcnn_selection_sort": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "prcnn_knn_point": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "prcnn_rpn_decode_proposals": (_i, [_i, _i, _i, _i, _i, _f, _f, _vp] + [_vp] * 9 + [_vp]),
+    "prcnn_bev_group_keep": (_i, [_i, _i, _vp, _vp, _vp, _d, _vp, _vp, _vp, _vp, _sz, _vp]),
     "prcnn_nms_aabb_batched": (_i, [_i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _sz, _vp]),
     "prcnn_pack_detections": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "prcnn_gather_point_grad_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -157,7 +157,7 @@ __device__ double rect_intersection(const BoxRec &p, const BoxRec &q)
 }
 
 // One wave per (row block, col block) of the upper triangle.
-__global__ __launch_bounds__(64) void mask_kernel(int n, int words, double thr,
+__global__ __launch_bounds__(64) void mask_kernel(int n, int words, double thr, double eps,
                                                   const BoxRec *__restrict__ rec_all,
                                                   unsigned long long *__restrict__ mask_all)
 {
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64) void mask_kernel(int n, int words, double thr,
             const BoxRec a = rec[rb * 64 + pr];
             const BoxRec &bq = colb[pk];
             const double ia = rect_intersection(a, bq);
-            const double iou = ia * 1.0 / (a.area + bq.area - ia + 0.0000001);   // nms_rotate.py:68
+            const double iou = ia * 1.0 / (a.area + bq.area - ia + eps);         // nms_rotate.py:68 (eps 1e-7)
             if (iou >= thr) atomicOr(&bits[pr], 1ull << pk);                       // :70
         }
         __syncthreads();
@@ -430,8 +430,138 @@ extern "C" int prcnn_nms_aabb_batched(int batch, int n, const float *boxes, cons
     return PRCNN_OK;
 }
 
+// ---- final detection de-dup: nms_on_bev / group_overlaps (test/test_frustum.py:185-218) ---------
+// Greedy grouping in index order: the first remaining detection collects every later remaining
+// detection whose rotated-BEV IoU with it is >= iou_threshold (get_iou :185-189: shapely polygon
+// intersection over union, no epsilon); the highest score of a group survives (stable sort,
+// :215: the earliest of equal scores).  BEV rectangle = corners 0..3 of compute_box_3d
+// (kitti/kitti_util.py:322-339): centre (x,z), length l along (cos ry, -sin ry), width w.
 namespace prcnn {
+
+__global__ __launch_bounds__(RANK_THREADS) void bev_rec_kernel(int n, const int *__restrict__ counts,
+                                                               const double *__restrict__ boxes_all,
+                                                               BoxRec *__restrict__ rec_all)
+{
+    const int i = blockIdx.x * RANK_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const size_t so = (size_t)blockIdx.z * n;
+    const int cnt = counts ? counts[blockIdx.z] : n;
+    const double *b = boxes_all + (so + i) * 5;
+    BoxRec r;
+    r.u = i < cnt ? b[0] : __builtin_nan("");        // NaN centre: never passes the circle screen
+    r.v = b[1];
+    double sn, cs;
+    sincos(b[4], &sn, &cs);
+    r.c = cs; r.s = -sn;
+    r.hw = 0.5 * b[2]; r.hh = 0.5 * b[3];
+    r.area = b[2] * b[3];
+    r.rad = sqrt(r.hw * r.hw + r.hh * r.hh);
+    rec_all[so + i] = r;
+}
+
+constexpr int GROUP_MAX_WORDS = 1024;   // n <= 65536 detections per frame
+
+__global__ __launch_bounds__(64) void bev_group_kernel(int n, int words, const int *__restrict__ counts,
+                                                       const unsigned long long *__restrict__ mask_all,
+                                                       const double *__restrict__ scores_all,
+                                                       int *__restrict__ group_all, int *__restrict__ keep_all,
+                                                       int *__restrict__ n_keep_all)
+{
+    __shared__ unsigned long long removed[GROUP_MAX_WORDS];
+    const size_t so = (size_t)blockIdx.x * n;
+    const unsigned long long *mask = mask_all + so * words;
+    const double *scores = scores_all + so;
+    int *group = group_all + so, *keep = keep_all + so;
+    const int lane = threadIdx.x;
+    const int cnt = min(n, max(0, counts ? counts[blockIdx.x] : n));
+    for (int w = lane; w < words; w += 64) {
+        const int valid = cnt - w * 64;
+        removed[w] = valid >= 64 ? 0ull : (valid <= 0 ? ~0ull : (~0ull << valid));
+    }
+    for (int i = cnt + lane; i < n; i += 64) group[i] = -1;
+    __syncthreads();
+    int ng = 0, cur = 0;
+    while (cur < cnt) {
+        int found = -1;
+        for (int w0 = cur >> 6; w0 < words && found < 0; w0 += 64) {
+            const int w = w0 + lane;
+            unsigned long long z = w < words ? ~removed[w] : 0ull;
+            if (w == (cur >> 6)) z &= ~0ull << (cur & 63);
+            const unsigned long long has = __ballot(z != 0ull);
+            if (has) {
+                const int fl = __builtin_ctzll(has);
+                found = (w0 + fl) * 64 + __builtin_ctzll(__shfl(z, fl));
+            }
+        }
+        if (found < 0 || found >= cnt) break;
+        // members = {found} + remaining later detections overlapping it; best = max score, earliest
+        const unsigned long long *row = mask + (size_t)found * words;
+        double bs = 0.0;
+        int bi = 0x7fffffff;
+        for (int w = (found >> 6) + lane; w < words; w += 64) {
+            unsigned long long mem = row[w] & ~removed[w];
+            if (w == (found >> 6)) mem |= 1ull << (found & 63);
+            removed[w] |= mem;
+            while (mem) {
+                const int i = w * 64 + __builtin_ctzll(mem);
+                mem &= mem - 1;
+                group[i] = ng;
+                const double s = scores[i];
+                if (bi == 0x7fffffff || s > bs) { bs = s; bi = i; }      // ascending i: first maximum
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double os = __shfl_xor(bs, off);
+            const int oi = __shfl_xor(bi, off);
+            const bool take = oi != 0x7fffffff && (bi == 0x7fffffff || os > bs || (os == bs && oi < bi));
+            if (take) { bs = os; bi = oi; }
+        }
+        // a group whose scores are all NaN keeps its first member, like Python's sort of NaNs may
+        if (lane == 0) keep[ng] = bi;
+        ++ng;
+        __syncthreads();
+        cur = found + 1;
+    }
+    for (int i = ng + lane; i < n; i += 64) keep[i] = -1;
+    if (lane == 0) n_keep_all[blockIdx.x] = ng;
+}
+
 }  // namespace prcnn
+
+extern "C" int prcnn_bev_group_keep(int frames, int n, const int *counts, const double *boxes,
+                                    const double *scores, double iou_threshold, int *group_id, int *keep,
+                                    int *n_keep, void *workspace, size_t workspace_bytes, prcnn_stream_t stream)
+{
+    using namespace prcnn;
+    if (n < 0 || frames < 0) return PRCNN_BAD_SHAPE;
+    if (frames == 0) return PRCNN_OK;
+    if (!n_keep) return PRCNN_BAD_SHAPE;
+    if (frames > 65535) return PRCNN_UNSUPPORTED;
+    if (!(iou_threshold > 0.0)) return PRCNN_UNSUPPORTED;      // 0 / NaN: every pair, not a de-dup
+    hipStream_t st = to_stream(stream);
+    if (n == 0) {
+        if (hipMemsetAsync(n_keep, 0, sizeof(int) * (size_t)frames, st) != hipSuccess) return PRCNN_HIP_ERROR;
+        return PRCNN_OK;
+    }
+    if (!boxes || !scores || !group_id || !keep) return PRCNN_BAD_SHAPE;
+    const NmsLayout L = nms_layout(frames, n);
+    if (L.words > GROUP_MAX_WORDS) return PRCNN_UNSUPPORTED;
+    if (!workspace || workspace_bytes < L.total) return PRCNN_WORKSPACE;
+    if (((uintptr_t)workspace & 255) != 0) return PRCNN_WORKSPACE;
+    char *ws = (char *)workspace;
+    BoxRec *rec = (BoxRec *)(ws + L.rec_off);
+    unsigned long long *mask = (unsigned long long *)(ws + L.mask_off);
+    const int iblocks = (n + RANK_THREADS - 1) / RANK_THREADS;
+    hipLaunchKernelGGL(bev_rec_kernel, dim3(iblocks, 1, frames), dim3(RANK_THREADS), 0, st, n, counts, boxes, rec);
+    const long long nblk = (long long)L.words * (L.words + 1) / 2;
+    hipLaunchKernelGGL(mask_kernel, dim3((unsigned)nblk, 1, frames), dim3(64), 0, st, n, L.words, iou_threshold,
+                       0.0, rec, mask);
+    hipLaunchKernelGGL(bev_group_kernel, dim3(frames), dim3(64), 0, st, n, L.words, counts, mask, scores,
+                       group_id, keep, n_keep);
+    PRCNN_LAUNCH_CHECK();
+    return PRCNN_OK;
+}
 
 extern "C" size_t prcnn_nms_rotate_batched_workspace_bytes(int batch, int n)
 {
@@ -489,7 +619,7 @@ extern "C" int prcnn_nms_rotate_batched(int batch, int n, const double *boxes, c
         const long long nblk = (long long)L.words * (L.words + 1) / 2;
         // only the upper triangle (incl. the diagonal blocks) is ever read by the sweep
         hipLaunchKernelGGL(mask_kernel, dim3((unsigned)nblk, 1, batch), dim3(64), 0, st, n, L.words,
-                           iou_threshold, rec, mask);
+                           iou_threshold, 0.0000001, rec, mask);
     } else {
         hipLaunchKernelGGL(mask_all_kernel, dim3(2048, 1, batch), dim3(64), 0, st, n, L.words, mask);
     }

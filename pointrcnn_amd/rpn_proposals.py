@@ -3,8 +3,10 @@ rotated NMS that the reference runs as TensorFlow graph ops.
 
   decode_proposals   = BoxEncoder.tf_decode (utils/box_encoder.py:109-179) + rpn.py:108-113
   reduce_proposals   = RPN.reduce_proposals (models/rpn.py:209-241)
-Both call one HIP kernel each (prcnn_rpn_decode_proposals, prcnn_nms_aabb_batched); there is no
-CPU fallback.
+  nms_on_bev         = nms_on_bev / group_overlaps (test/test_frustum.py:191-218), the final
+                       de-dup of the detections of a frame
+Each is one C-ABI call (prcnn_rpn_decode_proposals, prcnn_nms_aabb_batched,
+prcnn_bev_group_keep); there is no CPU fallback.
 """
 import ctypes
 
@@ -93,3 +95,36 @@ def reduce_proposals(end_points, max_output_size=300, iou_threshold=0.5):
     out = dict(end_points)
     out["nms_indices"] = idx
     return out
+
+
+def nms_on_bev(boxes, scores, counts=None, iou_threshold=0.1):
+    """test/test_frustum.py:206-218 for a batch of frames.  boxes (F,n,5) rows [x, z, l, w, ry]
+    (obj.t[0], obj.t[2], obj.l, obj.w, obj.ry), scores (F,n), counts (F,) detections present per
+    frame or None -> (group_id (F,n) int32, keep (F,n) int32 padded with -1, n_keep (F,) int32):
+    keep[f, g] is the surviving detection of group g, in the reference's output order."""
+    if not isinstance(boxes, torch.Tensor) or not boxes.is_cuda:
+        raise _lib.PointRCNNHipError("boxes must be a GPU tensor (no CPU path exists)")
+    if boxes.dim() != 3 or boxes.shape[-1] != 5:
+        raise ValueError("boxes must be (F,n,5)")
+    F, n, _ = boxes.shape
+    bx = boxes.to(torch.float64).contiguous()
+    sc = scores.to(torch.float64).contiguous()
+    if tuple(sc.shape) != (F, n) or not sc.is_cuda:
+        raise ValueError("scores must be a (F,n) GPU tensor")
+    cp = None
+    if counts is not None:
+        counts = counts.to(device=bx.device, dtype=torch.int32).contiguous()
+        if tuple(counts.shape) != (F,):
+            raise ValueError("counts must be (F,)")
+        cp = counts.data_ptr()
+    L = _lib.lib()
+    group = torch.empty((F, n), dtype=torch.int32, device=bx.device)
+    keep = torch.empty((F, n), dtype=torch.int32, device=bx.device)
+    nk = torch.empty(F, dtype=torch.int32, device=bx.device)
+    wsb = L.prcnn_nms_rotate_batched_workspace_bytes(F, n)
+    ws = torch.empty(wsb + 256, dtype=torch.uint8, device=bx.device)
+    off = (-ws.data_ptr()) % 256
+    _lib.check(L.prcnn_bev_group_keep(F, n, cp, bx.data_ptr(), sc.data_ptr(), float(iou_threshold), group.data_ptr(),
+                                      keep.data_ptr(), nk.data_ptr(), ws.data_ptr() + off, wsb,
+                                      torch.cuda.current_stream().cuda_stream), "bev_group_keep")
+    return group, keep, nk

@@ -55,3 +55,18 @@ def test_reduce_pads_with_minus_one():
         k = idx[b][idx[b] >= 0]
         assert len(set(k.tolist())) == len(k) and (np.diff(ep['proposal_scores'][b][k]) <= 0).all()
     assert (ep['proposal_scores'] > 0).all() and (ep['proposal_scores'] <= 1).all()
+
+
+def test_nms_on_bev_restatement_known_answers():
+    from oracle import oracle as O
+    a = [0, 10, 4, 2, 0.0]
+    assert abs(O.bev_iou(a, a) - 1.0) < 1e-12
+    assert abs(O.bev_iou(a, [2, 10, 4, 2, 0.0]) - 1.0 / 3.0) < 1e-12          # half overlap: 4/(8+8-4)
+    assert abs(O.bev_iou(a, [0, 10, 4, 2, np.pi]) - 1.0) < 1e-12
+    assert abs(O.bev_iou([0, 0, 2, 2, 0.0], [0, 0, 2, 2, np.pi / 4]) - (8 * (np.sqrt(2) - 1)) / (8 - 8 * (np.sqrt(2) - 1))) < 1e-12
+    assert O.bev_iou(a, [10, 10, 4, 2, 0.0]) == 0.0
+    det = np.array([a, [20, 10, 4, 2, 0.3], [0.5, 10, 4, 2, 0.0], [3.6, 10, 4, 2, 0.0], [20, 10, 4, 2, 0.3 + np.pi]])
+    g, k = O.nms_on_bev(det, [0.1, 0.5, 0.9, 0.2, 0.5])
+    assert g.tolist() == [0, 1, 0, 2, 1] and k.tolist() == [2, 1, 3]
+    g, k = O.nms_on_bev(np.zeros((0, 5)), np.zeros(0))
+    assert len(g) == 0 and len(k) == 0

@@ -73,3 +73,50 @@ def test_bad_arguments():
         P.decode_proposals(torch.zeros(1, 4, 50, device=DEV), torch.zeros(1, 4, 3, device=DEV))
     with pytest.raises(Exception):
         P.decode_proposals(torch.zeros(1, 4, 85), torch.zeros(1, 4, 3))
+
+
+def _detections(F, n, seed):
+    """clusters of near-duplicate detections, like the frustum stage's outputs on RPN proposals"""
+    rng = np.random.default_rng(seed)
+    det = np.zeros((F, n, 5))
+    ncl = max(1, n // 6)
+    for f in range(F):
+        cx, cz = rng.uniform(-30, 30, ncl), rng.uniform(3, 60, ncl)
+        ry = rng.uniform(-np.pi, np.pi, ncl)
+        c = rng.integers(0, ncl, n)
+        det[f, :, 0] = cx[c] + rng.normal(0, 0.4, n)
+        det[f, :, 1] = cz[c] + rng.normal(0, 0.4, n)
+        det[f, :, 2] = 3.9 * (1 + rng.normal(0, 0.1, n))
+        det[f, :, 3] = 1.6 * (1 + rng.normal(0, 0.1, n))
+        det[f, :, 4] = ry[c] + rng.normal(0, 0.2, n)
+    return det, rng.standard_normal((F, n))
+
+
+@pytest.mark.parametrize("F,n,thr", [(1, 1, 0.1), (3, 37, 0.1), (2, 200, 0.01), (4, 700, 0.1), (1, 64, 0.5)])
+def test_nms_on_bev_matches_restatement(F, n, thr):
+    from oracle import oracle as O
+    det, sc = _detections(F, n, 100 + n)
+    counts = np.array([n - (f * 5) % max(n, 1) if n > 20 else n for f in range(F)], np.int32)
+    sc[0, : n // 2] = np.round(sc[0, : n // 2], 1)            # equal scores inside groups
+    g, k, nk = P.nms_on_bev(torch.as_tensor(det).to(DEV), torch.as_tensor(sc).to(DEV), torch.as_tensor(counts), thr)
+    g, k, nk = g.cpu().numpy(), k.cpu().numpy(), nk.cpu().numpy()
+    for f in range(F):
+        c = int(counts[f])
+        wg, wk, margin = O.nms_on_bev(det[f, :c], sc[f, :c], thr, return_margin=True)
+        assert margin > 1e-9, "fixture has a pair within float noise of the threshold"
+        assert nk[f] == len(wk)
+        assert np.array_equal(k[f, :nk[f]], wk) and (k[f, nk[f]:] == -1).all()
+        assert np.array_equal(g[f, :c], wg) and (g[f, c:] == -1).all()
+    assert (nk < counts).any() or n == 1                       # the fixture does merge something
+
+
+def test_nms_on_bev_known_answers():
+    # 0 and 2 overlap heavily, 1 is apart, 3 touches 0 only slightly (IoU 1/19 < 0.1), 4 == 1 rotated by pi
+    det = np.array([[[0, 10, 4, 2, 0.0], [20, 10, 4, 2, 0.3], [0.5, 10, 4, 2, 0.0], [3.6, 10, 4, 2, 0.0],
+                     [20, 10, 4, 2, 0.3 + np.pi]]])
+    sc = np.array([[0.1, 0.5, 0.9, 0.2, 0.5]])
+    g, k, nk = P.nms_on_bev(torch.as_tensor(det).to(DEV), torch.as_tensor(sc).to(DEV))
+    assert g[0].cpu().tolist() == [0, 1, 0, 2, 1]
+    assert int(nk[0]) == 3 and k[0].cpu().tolist() == [2, 1, 3, -1, -1]     # equal scores: the earlier one
+    with pytest.raises(Exception):
+        P.nms_on_bev(torch.as_tensor(det).to(DEV), torch.as_tensor(sc).to(DEV), None, 0.0)

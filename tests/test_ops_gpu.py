@@ -36,6 +36,28 @@ def test_fps_bit_exact_sizes(cuda, n, m):
     assert np.array_equal(got, O.farthest_point_sample(m, pts))
 
 
+@pytest.mark.parametrize("n,m", [(4097, 256), (5000, 300), (8192, 1000), (12000, 256), (16383, 700), (16384, 2048)])
+def test_fps_pruned_kernel_sizes(cuda, n, m):
+    """n > 4096 and m >= 256 run the bucket-pruned kernel (grid-sorted cloud, skipped buckets):
+    same indices as the plain kernel and the oracle, duplicates and ragged last bucket included."""
+    pts = S.kitti_scene(3000 + n, n, max(64, int(n * 1.15)))[None, :, :3]
+    pts = np.concatenate([pts, S.kitti_scene(4000 + n, n, max(64, n // 5))[None, :, :3]], 0)
+    got = npy(ops.farthest_point_sample(m, dev(pts, cuda)))
+    assert np.array_equal(got, O.farthest_point_sample(m, pts))
+
+
+def test_fps_pruned_kernel_degenerate_clouds(cuda):
+    rng = np.random.default_rng(5)
+    n, m = 6000, 300
+    same = np.tile(np.array([[1.5, -2.0, 30.0]], np.float32), (n, 1))          # every distance 0
+    line = np.zeros((n, 3), np.float32); line[:, 2] = rng.permutation(n) * 0.01   # two empty axes
+    plane = rng.uniform(-20, 20, (n, 3)).astype(np.float32); plane[:, 1] = 1.65
+    lattice = (rng.integers(0, 12, (n, 3)) * 0.5).astype(np.float32)              # masses of exact ties
+    pts = np.stack([same, line, plane, lattice])
+    got = npy(ops.farthest_point_sample(m, dev(pts, cuda)))
+    assert np.array_equal(got, O.farthest_point_sample(m, pts))
+
+
 def test_fps_golden_tiebreak_and_duplicates(cuda, golden_dir):
     g = np.load(os.path.join(golden_dir, "fps_transcription.npz"))
     assert np.array_equal(npy(ops.farthest_point_sample(400, dev(g["cloud"], cuda))), g["idx_dup"])

@@ -181,6 +181,18 @@ int prcnn_sa_group_mlp_layer(int b, int n, int m, int nsample, int c, const floa
                              const float *shift, int relu, int pool, int precision,
                              float *out, int64_t ldo, prcnn_stream_t stream);
 
+/* The same first layer with its feature half hoisted out of the grouping (additive; exact algebra,
+ * fp32 re-association): the convolution is linear, so  [feats[idx], xyz[idx]-new_xyz] . W  =
+ * (feats . W_feat)[idx] + (xyz[idx]-new_xyz) . W_xyz.  `table` (b*n rows of ldt floats, cout used)
+ * holds feats . W_feat per POINT (one prcnn_mlp_layer over b*n rows instead of b*m*nsample
+ * grouped rows); this call gathers table rows by idx, adds the 3-column xyz product (w_xyz is
+ * (3, cout)) and applies the epilogue of prcnn_mlp_layer. */
+int prcnn_sa_group_add_layer(int b, int n, int m, int nsample, const float *xyz,
+                             const float *new_xyz, const int *idx, const float *table,
+                             int64_t ldt, int cout, const float *w_xyz, const float *scale,
+                             const float *shift, int relu, int pool, int precision, float *out,
+                             int64_t ldo, prcnn_stream_t stream);
+
 /* A whole set-abstraction scale in one launch for NARROW layers: grouping + three shared-MLP
  * layers + max over nsample (pointnet_util.py:177-192 for one radius; :43-53,116-126 for
  * SSG), fp32 matrix cores, no intermediate activation in HBM.  Serves c+3 <= 8, c1,c2 <= 32,

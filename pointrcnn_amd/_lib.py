@@ -38,6 +38,8 @@ SIGNATURES = {
     "prcnn_nms_rotate_batched_workspace_bytes": (_sz, [_i, _i]),
     "prcnn_nms_rotate_batched": (_i, [_i, _i, _vp, _vp, _d, _i, _vp, _vp, _vp, _sz, _vp]),
     "prcnn_mlp_layer": (_i, [_i64, _i, _i, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp]),
+    "prcnn_sa_group_add_layer": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _i, _i, _i,
+                                      _vp, _i64, _vp]),
     "prcnn_sa_group_mlp_layer": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp,
                                       _i, _i, _i, _vp, _i64, _vp]),
     "prcnn_sa_group_mlp3_pool": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i] + [_vp] * 9 +

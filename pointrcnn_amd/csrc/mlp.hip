@@ -40,6 +40,11 @@ struct MlpArgs {
     int n, m, ns, c, xyz_first;
     const float *xyz, *feats, *new_xyz;
     const int *idx;
+    // gather prologue only: per-point rows added to the accumulators before scale/shift
+    // (the feature half of a first SA layer, evaluated once per point instead of once per
+    // grouped row): acc[row][col] += add[(bi*n + idx[row]) * ldadd + col]
+    const float *add;
+    long long ldadd;
 };
 
 constexpr int MLP_THREADS = 256;
@@ -112,7 +117,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
 
 // ---- kernel ---------------------------------------------------------------------------
 // WM x WN waves (WM*WN == 4), each wave owns TM x TN MFMA tiles of 32x32.
-template <int WM, int WN, int TM, int TN, bool GATHER, bool BF16, int KB>
+template <int WM, int WN, int TM, int TN, bool GATHER, bool BF16, int KB, bool ADD = false>
 __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void mlp_kernel(const MlpArgs a)
 {
     constexpr int BN = WN * TN * 32;
@@ -131,6 +136,7 @@ __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     __shared__ __attribute__((aligned(16))) unsigned lds[LDS_WORDS];
     unsigned *As = lds;
     unsigned *Bs = lds + A_WORDS;
+    __shared__ long long rowpt[ADD ? BM : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -143,6 +149,7 @@ __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     constexpr int A_PER = BK / 2;                    // elements per thread
     const int arow = tid >> 1, ahalf = tid & 1;
     const RowSrc rs = make_row<GATHER>(a, row0 + arow);
+    if (ADD && ahalf == 0) rowpt[arow] = rs.valid ? rs.pi : -1;   // read after the K loop's barriers
     const bool a_vec = GATHER ? ((a.c & 3) == 0 && (((uintptr_t)a.feats) & 15) == 0)
                               : ((a.ldx & 3) == 0 && (((uintptr_t)a.x) & 15) == 0);
     // B: BK x BN elements; thread -> k = tid / (BN/BPT), n-offset
@@ -302,6 +309,22 @@ __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         sc[j] = cok[j] ? a.scale[col] : 0.f;
         sh[j] = cok[j] ? a.shift[col] : 0.f;
     }
+    if constexpr (ADD) {
+        // rowpt[] (written before the K loop by the thread that staged the row) = point row of
+        // each of the tile's 128 grouped rows, -1 past the end
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long pt = rowpt[(wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh];
+                const float *src = a.add + (pt < 0 ? 0 : pt) * a.ldadd + col0 + li;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float v = (cok[j] && pt >= 0) ? src[(wn * TN + j) * 32] : 0.f;
+                    acc[i][j][r] += v;
+                }
+            }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -386,6 +409,18 @@ static int launch_mlp(const MlpArgs &a, hipStream_t st)
     // amortise the A staging best when K is large or the grid is many rounds deep; 64 columns
     // (4 waves/SIMD instead of 3, twice the workgroups) win on shallow grids; never pad a
     // narrow layer up to a wide tile.
+    if (GATHER && a.add) {
+        // gather + 3-column product: memory-bound, the narrow tiles (no spills with the gather
+        // epilogue) are the right ones whatever cout is
+        const int bn = a.cout <= 32 ? 32 : 64;
+        dim3 grid((unsigned)rb, (a.cout + bn - 1) / bn);
+        if (bn == 32)
+            hipLaunchKernelGGL((mlp_kernel<4, 1, 1, 1, GATHER, BF16, BF16 ? 32 : 16, GATHER>), grid, dim3(MLP_THREADS), 0, st, a);
+        else
+            hipLaunchKernelGGL((mlp_kernel<4, 1, 1, 2, GATHER, BF16, BF16 ? 32 : 16, GATHER>), grid, dim3(MLP_THREADS), 0, st, a);
+        PRCNN_LAUNCH_CHECK();
+        return PRCNN_OK;
+    }
     int bn;
     const long long wgs128 = rb * ((a.cout + 127) / 128);
     if (a.cout <= 32) bn = 32;
@@ -461,6 +496,29 @@ extern "C" int prcnn_sa_group_mlp_layer(int b, int n, int m, int nsample, int c,
     a.relu = relu; a.pool = pool; a.out = out; a.ldo = ldo;
     a.n = n; a.m = m; a.ns = nsample; a.c = c; a.xyz_first = xyz_first;
     a.xyz = xyz; a.feats = feats; a.new_xyz = new_xyz; a.idx = idx;
+    return precision ? launch_mlp<true, true>(a, to_stream(stream))
+                     : launch_mlp<true, false>(a, to_stream(stream));
+}
+
+extern "C" int prcnn_sa_group_add_layer(int b, int n, int m, int nsample, const float *xyz,
+                                        const float *new_xyz, const int *idx, const float *table,
+                                        int64_t ldt, int cout, const float *w_xyz, const float *scale,
+                                        const float *shift, int relu, int pool, int precision, float *out,
+                                        int64_t ldo, prcnn_stream_t stream)
+{
+    using namespace prcnn;
+    if (b < 0 || n <= 0 || m < 0 || nsample <= 0) return PRCNN_BAD_SHAPE;
+    const long long rows = (long long)b * m * nsample;
+    int rc = check_common(rows, 3, cout, w_xyz, scale, shift, pool, precision, out, ldo);
+    if (rc != PRCNN_OK) return rc;
+    if (rows == 0) return PRCNN_OK;
+    if (!xyz || !new_xyz || !idx || !table || ldt < cout) return PRCNN_BAD_SHAPE;
+    MlpArgs a = {};
+    a.rows = rows; a.cin = 3; a.cout = cout; a.w = w_xyz; a.scale = scale; a.shift = shift;
+    a.relu = relu; a.pool = pool; a.out = out; a.ldo = ldo;
+    a.n = n; a.m = m; a.ns = nsample; a.c = 0; a.xyz_first = 1;
+    a.xyz = xyz; a.feats = nullptr; a.new_xyz = new_xyz; a.idx = idx;
+    a.add = table; a.ldadd = ldt;
     return precision ? launch_mlp<true, true>(a, to_stream(stream))
                      : launch_mlp<true, false>(a, to_stream(stream));
 }

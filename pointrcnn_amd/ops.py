@@ -442,6 +442,44 @@ def sa_group_mlp_layer(xyz, feats, new_xyz, idx, w, scale, shift, xyz_first=Fals
     return out
 
 
+def sa_group_add_layer(xyz, new_xyz, idx, table, col, cout, w_xyz, scale, shift, relu=True, pool=1,
+                       precision=PRECISION_FP32):
+    """First SA layer with the feature half hoisted out of the grouping: `table` (b,n,ctab) holds
+    feats . W_feat per point in columns [col, col+cout); this gathers its rows by idx, adds
+    (xyz[idx]-new_xyz) . w_xyz (3,cout) and applies scale/shift/ReLU (and the max-pool).
+    Returns (b,m,nsample,cout), or (b,m,cout) when pool == nsample."""
+    xyz = _dev(xyz, torch.float32, "sa_group_add_layer xyz", 3, 3)
+    new_xyz = _dev(new_xyz, torch.float32, "sa_group_add_layer new_xyz", 3, 3)
+    idx = _dev(idx, torch.int32, "sa_group_add_layer idx", 3)
+    table = _dev(table, torch.float32, "sa_group_add_layer table", 3)
+    w_xyz = _dev(w_xyz, torch.float32, "sa_group_add_layer w_xyz", 2)
+    scale = _dev(scale, torch.float32, "scale", 1)
+    shift = _dev(shift, torch.float32, "shift", 1)
+    b, n, _ = xyz.shape
+    _, m, ns = idx.shape
+    ctab = table.shape[2]
+    if table.shape[0] != b or table.shape[1] != n or col < 0 or col + cout > ctab:
+        raise ValueError("sa_group_add_layer: table %s does not hold columns [%d,%d) for %d x %d points"
+                         % (tuple(table.shape), col, col + cout, b, n))
+    if tuple(w_xyz.shape) != (3, cout):
+        raise ValueError("sa_group_add_layer: w_xyz must be (3,%d)" % cout)
+    if pool > 1:
+        if pool != ns:
+            raise ValueError("sa_group_add_layer: pool must equal nsample")
+        out = torch.empty((b, m, cout), dtype=torch.float32, device=xyz.device)
+    else:
+        out = torch.empty((b, m, ns, cout), dtype=torch.float32, device=xyz.device)
+    rows = b * m * ns
+    _lib.check(_run("sa_group_add_layer", {"shape": "rows%d N%d pool%d" % (rows, cout, pool),
+                                           "flops": 2 * rows * 3 * cout,
+                                           "bytes": rows * (4 + 12 + 4 * cout) + 4 * (rows // pool) * cout},
+                    lambda: _lib.lib().prcnn_sa_group_add_layer(
+        b, n, m, ns, _p(xyz), _p(new_xyz), _p(idx), table.data_ptr() + 4 * col, ctab, cout, _p(w_xyz),
+        _p(scale), _p(shift), int(relu), int(pool), int(precision), _p(out), cout, _stream())),
+        "sa_group_add_layer")
+    return out
+
+
 def sa_chain_supported(c, mlp, nsample, precision):
     """Shapes the fully fused set-abstraction kernel serves (see prcnn_sa_group_mlp3_pool)."""
     return (precision == PRECISION_FP32 and len(mlp) == 3 and c + 3 <= 8 and mlp[0] <= 32

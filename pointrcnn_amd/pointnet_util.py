@@ -44,6 +44,18 @@ class ParamStore(dict):
             self[key] = torch.zeros(n, dtype=torch.float32, device=self.device)
         return self[key]
 
+    def ones(self, n):
+        key = '__ones_%d' % n
+        if key not in self:
+            self[key] = torch.ones(n, dtype=torch.float32, device=self.device)
+        return self[key]
+
+    def derived(self, key, make):
+        """Tensors derived from stored layers (weight slices / concatenations), built once."""
+        if key not in self:
+            self[key] = make()
+        return self[key]
+
     def layer(self, name, cin, cout, bn=True):
         if name not in self:
             lim = math.sqrt(6.0 / (cin + cout))                     # xavier_initializer
@@ -64,6 +76,7 @@ class ParamStore(dict):
         return W, s, t
 
 
+SA_SPLIT = True      # hoist the feature half of the first MSG layer out of the grouping (pointnet_sa_module_msg)
 FP_SPLIT = True      # split the first FP convolution around the interpolation (pointnet_fp_module)
 
 
@@ -208,6 +221,29 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
     c_feat = 0 if points is None else points.shape[2]
     # FUSED: one pass over the points answers the ball queries of every scale
     balls = ops.query_ball_point_msg(radius_list, nsample_list, xyz, new_xyz) if FUSED else None
+    # SA_SPLIT: the first convolution is linear, so its feature half is evaluated once per POINT
+    # for all scales together (b*n rows x c_feat x sum c1) instead of once per grouped row
+    # (b*m*nsample rows per scale); the grouped layer then gathers those rows and adds the
+    # 3-column xyz product:  [f[idx], xyz[idx]-c] W = (f W_f)[idx] + (xyz[idx]-c) W_x.
+    # Same value up to fp32 re-association (tolerance tier, like every MLP output).
+    split = [FUSED and SA_SPLIT and use_xyz and points is not None and ns_ % 16 == 0 and 128 % ns_ == 0
+             and not ops.sa_chain_supported(c_feat, mlp_, ns_, precision)
+             for ns_, mlp_ in zip(nsample_list, mlp_list)]
+    table, tcol = None, {}
+    if any(split):
+        names = ['%s/conv%d_0' % (scope, i) for i in range(len(radius_list)) if split[i]]
+        for i in range(len(radius_list)):
+            if split[i]:
+                store.layer('%s/conv%d_0' % (scope, i), c_feat + 3, mlp_list[i][0], bn)
+        wf = store.derived('__wf/' + '|'.join(names),
+                           lambda: torch.cat([store[nm][0][:c_feat] for nm in names], dim=1).contiguous())
+        o = 0
+        for i in range(len(radius_list)):
+            if split[i]:
+                tcol[i] = o
+                o += mlp_list[i][0]
+        table = ops.mlp_layer(points.reshape(b * points.shape[1], c_feat), wf, store.ones(o), store.zeros(o),
+                              relu=False, precision=precision).reshape(b, points.shape[1], o)
     for i in range(len(radius_list)):
         radius, nsample, mlp = radius_list[i], nsample_list[i], mlp_list[i]
         idx, pts_cnt = balls[i] if balls is not None else ops.query_ball_point(radius, nsample, xyz, new_xyz)
@@ -219,7 +255,15 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
             ops.sa_group_mlp3_pool(xyz, points, new_xyz, idx, layers, xyz_first=False, out=out, out_col=col)
             col += mlp[-1]
             continue
-        if fusable:
+        if fusable and split[i]:
+            name = '%s/conv%d_0' % (scope, i)
+            W, s, t = store.layer(name, c_feat + 3, mlp[0], bn)
+            wx = store.derived('__wx/' + name, lambda: W[c_feat:].contiguous())
+            x = ops.sa_group_add_layer(xyz, new_xyz, idx, table, tcol[i], mlp[0], wx, s, t, relu=True,
+                                       pool=nsample if len(mlp) == 1 else 1, precision=precision)
+            x = x.reshape(-1, mlp[0])
+            start, c = 1, mlp[0]
+        elif fusable:
             W, s, t = store.layer('%s/conv%d_0' % (scope, i), c_feat + 3, mlp[0], bn)
             x = ops.sa_group_mlp_layer(xyz, points, new_xyz, idx, W, s, t, xyz_first=False, relu=True,
                                        pool=nsample if len(mlp) == 1 else 1, precision=precision)

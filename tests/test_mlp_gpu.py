@@ -91,6 +91,39 @@ def test_sa_group_mlp_layer_equals_materialised_path(cuda, prec, c, xyz_first, n
     close(got, O.max_pool(ref, ns), prec)
 
 
+@pytest.mark.parametrize("prec", [ops.PRECISION_FP32, ops.PRECISION_BF16])
+@pytest.mark.parametrize("c,ns,couts", [(96, 16, (64, 64)), (256, 32, (128, 128)), (5, 16, (40,)), (512, 32, (256, 7))])
+def test_sa_group_add_layer_equals_concat_layer(cuda, prec, c, ns, couts):
+    """The hoisted form  (f W_f)[idx] + (xyz[idx]-c) W_x  against the oracle's concat convolution
+    [f[idx], xyz[idx]-c] W, scales sharing one per-point table (tolerance tier of the precision)."""
+    rng = np.random.default_rng(c + ns)
+    b, n, m = 2, 600, 37                                    # ragged last tile, m*ns not a multiple of 128
+    xyz = (rng.random((b, n, 3), dtype=np.float32) * np.float32(40.0))   # KITTI-sized coordinates
+    feats = rng.standard_normal((b, n, c)).astype(np.float32)
+    fi = O.farthest_point_sample(m, xyz)
+    new_xyz = O.gather_point(xyz, fi)
+    idx, _ = O.query_ball_point(6.0, ns, xyz, new_xyz)
+    layers = [rand_layer(rng, c + 3, co) for co in couts]
+    wf = np.concatenate([W[:c] for W, _, _ in layers], 1)
+    ctab = wf.shape[1]
+    table = ops.mlp_layer(dev(feats.reshape(b * n, c), cuda), dev(wf, cuda), torch.ones(ctab, device=cuda),
+                          torch.zeros(ctab, device=cuda), relu=False, precision=prec).reshape(b, n, ctab)
+    rows = np.concatenate([O.group_point(feats, idx), O.group_point(xyz, idx) - new_xyz[:, :, None, :]], -1)
+    col = 0
+    for (W, s, t), co in zip(layers, couts):
+        ref = O.mlp_layer(rows, W, s, t)
+        args = (dev(xyz, cuda), dev(new_xyz, cuda), dev(idx, cuda), table, col, co, dev(W[c:].copy(), cuda),
+                dev(s, cuda), dev(t, cuda))
+        got = npy(ops.sa_group_add_layer(*args, precision=prec))
+        assert got.shape == (b, m, ns, co)
+        close(got, ref, prec)
+        close(npy(ops.sa_group_add_layer(*args, pool=ns, precision=prec)), O.max_pool(ref, ns), prec)
+        col += co
+    with pytest.raises(ValueError):
+        ops.sa_group_add_layer(dev(xyz, cuda), dev(new_xyz, cuda), dev(idx, cuda), table, ctab - 1, 8,
+                               torch.zeros(3, 8, device=cuda), torch.ones(8, device=cuda), torch.zeros(8, device=cuda))
+
+
 @pytest.mark.parametrize("c,xyz_first,ns,mlp", [(1, False, 16, [16, 16, 32]), (1, False, 32, [32, 32, 64]),
                                                  (0, True, 16, [20, 8, 100]), (4, True, 32, [32, 32, 128]),
                                                  (5, False, 16, [7, 32, 33])])

@@ -152,7 +152,7 @@ def cpu_baseline(store, seconds_cap=40.0):
     from oracle import oracle as O
     from oracle import stack as ostack
     O.lib()
-    params = {k: tuple(t.detach().cpu().numpy() for t in v) for k, v in store.items()}
+    params = {k: tuple(t.detach().cpu().numpy() for t in v) for k, v in store.items() if not k.startswith('__')}
     timers = {}
     nscenes, dt = 0, 0.0
     while dt < 10.0 and nscenes < 16:                            # bounded sample: ~10-30 s of CPU work
@@ -319,7 +319,7 @@ def main():
             if "flops" in d:
                 peak = roofline.FP32_MFMA_PEAK_TFLOPS if precision == 0 else roofline.BF16_MFMA_PEAK_TFLOPS
                 e.update(bound="mfma", achieved=d["flops"] / (d["ms"] * 1e-3) / 1e12, peak=peak, unit="TFLOP/s")
-            elif name in ("group_point", "three_interpolate", "three_nn_interpolate", "gather_point"):
+            elif name in ("group_point", "three_interpolate", "three_nn_interpolate", "gather_point", "sa_group_add_layer"):
                 e.update(bound="hbm", achieved=d["bytes"] / (d["ms"] * 1e-3) / 1e9, peak=roofline.HBM_PEAK_GBS,
                          unit="GB/s")
             if "achieved" in e:
@@ -336,8 +336,8 @@ def main():
                 peak = roofline.FP32_MFMA_PEAK_TFLOPS if precision == 0 else roofline.BF16_MFMA_PEAK_TFLOPS
                 cand = dict(kernel=name, shape=d.get("shape"), bound="mfma", unit="TFLOP/s", peak=peak,
                             achieved=d["flops"] / (d["ms"] * 1e-3) / 1e12, algorithmic=d["flops"] // d["launches"])
-            elif name in ("group_point", "three_interpolate"):
-                cand = dict(kernel=name, shape=None, bound="hbm", unit="GB/s", peak=roofline.HBM_PEAK_GBS,
+            elif name in ("group_point", "three_interpolate", "sa_group_add_layer"):
+                cand = dict(kernel=name, shape=d.get("shape"), bound="hbm", unit="GB/s", peak=roofline.HBM_PEAK_GBS,
                             achieved=d["bytes"] / (d["ms"] * 1e-3) / 1e9, algorithmic=d["bytes"] // d["launches"])
             else:
                 continue

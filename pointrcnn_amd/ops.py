@@ -470,8 +470,8 @@ def sa_group_add_layer(xyz, new_xyz, idx, table, col, cout, w_xyz, scale, shift,
     else:
         out = torch.empty((b, m, ns, cout), dtype=torch.float32, device=xyz.device)
     rows = b * m * ns
+    # memory-bound gather (3-column product aside): declared by its bytes, not flops
     _lib.check(_run("sa_group_add_layer", {"shape": "rows%d N%d pool%d" % (rows, cout, pool),
-                                           "flops": 2 * rows * 3 * cout,
                                            "bytes": rows * (4 + 12 + 4 * cout) + 4 * (rows // pool) * cout},
                     lambda: _lib.lib().prcnn_sa_group_add_layer(
         b, n, m, ns, _p(xyz), _p(new_xyz), _p(idx), table.data_ptr() + 4 * col, ctab, cout, _p(w_xyz),

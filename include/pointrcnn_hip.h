@@ -240,6 +240,17 @@ int prcnn_three_nn_interpolate_add(int b, int n, int m, int c, const float *xyz1
                                    int64_t ldo, int relu, void *workspace, size_t workspace_bytes,
                                    prcnn_stream_t stream);
 
+/* The same with the added term evaluated in the epilogue instead of being read from `out`
+ * (additive): out[q][:c] = act(interpolate(points2)[q] + p1[q][:c1] . u + t) with p1 (b,n,c1),
+ * u (c1,c), t (c), c1 <= 4 (c1 == 0: t only).  It is the points1 half of the split first FP
+ * convolution (pointnet_util.py:218-226) when points1 is narrow (the RPN's last FP level
+ * concatenates the 1-channel intensity): no (b,n,c) tensor is written and read back. */
+int prcnn_three_nn_interpolate_affine(int b, int n, int m, int c, const float *xyz1,
+                                      const float *xyz2, const float *points2, const float *p1,
+                                      int c1, const float *u, const float *t, float *out,
+                                      int64_t ldo, int relu, void *workspace,
+                                      size_t workspace_bytes, prcnn_stream_t stream);
+
 /* out[:, :c] = out[:, :c] + three_interpolate(points, idx, weight) (then ReLU if relu != 0),
  * rows of out at out + r*ldo: the element-parallel form of the epilogue above, for levels
  * whose search is small (idx / weight from prcnn_three_nn + prcnn_fp_weights). */

@@ -48,6 +48,8 @@ SIGNATURES = {
     "prcnn_three_nn_sorted_workspace_bytes": (_sz, [_i, _i, _i]),
     "prcnn_three_nn_sorted": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "prcnn_three_nn_interpolate_sorted": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "prcnn_three_nn_interpolate_affine": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i64, _i,
+                                               _vp, _sz, _vp]),
     "prcnn_three_nn_interpolate_add": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i, _vp, _sz, _vp]),
     "prcnn_three_interpolate_add": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
     "prcnn_query_ball_point_sorted_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -62,6 +62,31 @@ __device__ __forceinline__ int wave_max_i32(int v)
 __device__ __forceinline__ int f2i(float f) { return __builtin_bit_cast(int, f); }
 __device__ __forceinline__ float i2f(int i) { return __builtin_bit_cast(float, i); }
 
+// ---- affine epilogue of the fused interpolation ------------------------------------------------
+// out[q][col] = act(interp[q][col] + sum_k p1[q][k] * u[k][col] + t[col]), k < c1 <= 4: the
+// "points1" half of a split FP convolution when points1 is narrow (e.g. the intensity channel),
+// evaluated in the epilogue instead of being written to and re-read from HBM.  p1 == nullptr
+// with c1 == 0 adds t only.
+struct EpiAffine {
+    const float *p1, *u, *t;
+    int c1;
+};
+
+template <int VEC>
+__device__ __forceinline__ void epi_affine_add(const EpiAffine &a, size_t row, int c, int col, float *v)
+{
+    float x[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) x[q] = a.t[col + q];
+    for (int k = 0; k < a.c1; ++k) {
+        const float pv = a.p1[row * a.c1 + k];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) x[q] += pv * a.u[(size_t)k * c + col + q];
+    }
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) v[q] += x[q];
+}
+
 // ---- three smallest (distance, index) pairs, branch-free -----------------------------------
 // threenn_cpu (tf_interpolate.cpp:74-89) inserts with strict '<' while the index increases,
 // i.e. it keeps the three smallest pairs under the lexicographic order (distance, index).

@@ -170,7 +170,7 @@ template <int VEC>
 __global__ __launch_bounds__(FU_THREADS) void three_nn_interpolate_kernel(
     int n, int m, int c, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
     const float *__restrict__ points2, float *__restrict__ out, long long ldo,
-    float *__restrict__ dist, int *__restrict__ idx, int epi)
+    float *__restrict__ dist, int *__restrict__ idx, int epi, EpiAffine aff)
 {
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
     __shared__ PairTile tile;
@@ -215,7 +215,14 @@ __global__ __launch_bounds__(FU_THREADS) void three_nn_interpolate_kernel(
         const vec_t cc = *reinterpret_cast<const vec_t *>(pb + (size_t)s_i[r * 3 + 2] * c + col);
         vec_t v = a * s_w[r * 3] + bb * s_w[r * 3 + 1] + cc * s_w[r * 3 + 2];
         vec_t *op = reinterpret_cast<vec_t *>(out + ((size_t)bi * n + j0 + r) * ldo + col);
-        if (epi) {                                   // 1: out += v;  2: out = relu(out + v)
+        if (epi >= 3) {                              // 3: affine + relu;  4: affine (EpiAffine)
+            float vv[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) vv[q] = v[q];
+            epi_affine_add<VEC>(aff, (size_t)bi * n + j0 + r, c, col, vv);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) v[q] = epi == 3 ? fmaxf(vv[q], 0.f) : vv[q];
+        } else if (epi) {                            // 1: out += v;  2: out = relu(out + v)
             v = *op + v;
             if (epi == 2) {
 #pragma unroll
@@ -300,7 +307,7 @@ extern "C" int prcnn_three_interpolate_add(int b, int m, int c, int n, const flo
 
 static int launch_fused_nn(int b, int n, int m, int c, const float *xyz1, const float *xyz2,
                            const float *points2, float *out, int64_t ldo, float *dist, int *idx, int epi,
-                           prcnn_stream_t stream)
+                           prcnn_stream_t stream, prcnn::EpiAffine aff = prcnn::EpiAffine{})
 {
     using namespace prcnn;
     if (b < 0 || n < 0 || m <= 0 || c <= 0 || ldo < c) return PRCNN_BAD_SHAPE;
@@ -312,10 +319,10 @@ static int launch_fused_nn(int b, int n, int m, int c, const float *xyz1, const 
     const bool a16 = (((uintptr_t)points2 | (uintptr_t)out) & 15) == 0 && ldo % 4 == 0;
     if (c % 4 == 0 && a16)
         hipLaunchKernelGGL(three_nn_interpolate_kernel<4>, grid, dim3(FU_THREADS), 0, st, n, m, c, xyz1,
-                           xyz2, points2, out, (long long)ldo, dist, idx, epi);
+                           xyz2, points2, out, (long long)ldo, dist, idx, epi, aff);
     else
         hipLaunchKernelGGL(three_nn_interpolate_kernel<1>, grid, dim3(FU_THREADS), 0, st, n, m, c, xyz1,
-                           xyz2, points2, out, (long long)ldo, dist, idx, epi);
+                           xyz2, points2, out, (long long)ldo, dist, idx, epi, aff);
     PRCNN_LAUNCH_CHECK();
     return PRCNN_OK;
 }
@@ -329,8 +336,8 @@ extern "C" int prcnn_three_nn_interpolate(int b, int n, int m, int c, const floa
 
 // declared in nn_sorted.hip
 int prcnn_ns_fused(int b, int n, int m, int c, const float *xyz1, const float *xyz2, const float *points2,
-                   float *out, int64_t ldo, float *dist, int *idx, int epi, void *ws, size_t ws_bytes,
-                   prcnn_stream_t stream);
+                   float *out, int64_t ldo, float *dist, int *idx, int epi, const prcnn::EpiAffine *aff,
+                   void *ws, size_t ws_bytes, prcnn_stream_t stream);
 
 extern "C" int prcnn_three_nn_interpolate_add(int b, int n, int m, int c, const float *xyz1,
                                               const float *xyz2, const float *points2, float *out,
@@ -339,7 +346,23 @@ extern "C" int prcnn_three_nn_interpolate_add(int b, int n, int m, int c, const 
 {
     const int epi = relu ? 2 : 1;
     if (workspace)
-        return prcnn_ns_fused(b, n, m, c, xyz1, xyz2, points2, out, ldo, nullptr, nullptr, epi, workspace,
+        return prcnn_ns_fused(b, n, m, c, xyz1, xyz2, points2, out, ldo, nullptr, nullptr, epi, nullptr, workspace,
                               workspace_bytes, stream);
     return launch_fused_nn(b, n, m, c, xyz1, xyz2, points2, out, ldo, nullptr, nullptr, epi, stream);
+}
+
+extern "C" int prcnn_three_nn_interpolate_affine(int b, int n, int m, int c, const float *xyz1,
+                                                 const float *xyz2, const float *points2, const float *p1,
+                                                 int c1, const float *u, const float *t, float *out,
+                                                 int64_t ldo, int relu, void *workspace,
+                                                 size_t workspace_bytes, prcnn_stream_t stream)
+{
+    if (c1 < 0 || c1 > 4) return PRCNN_UNSUPPORTED;
+    if (!t || (c1 > 0 && (!p1 || !u))) return PRCNN_BAD_SHAPE;
+    prcnn::EpiAffine aff = {p1, u, t, c1};
+    const int epi = relu ? 3 : 4;
+    if (workspace)
+        return prcnn_ns_fused(b, n, m, c, xyz1, xyz2, points2, out, ldo, nullptr, nullptr, epi, &aff, workspace,
+                              workspace_bytes, stream);
+    return launch_fused_nn(b, n, m, c, xyz1, xyz2, points2, out, ldo, nullptr, nullptr, epi, stream, aff);
 }

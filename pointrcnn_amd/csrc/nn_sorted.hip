@@ -226,7 +226,8 @@ __global__ __launch_bounds__(NS_THREADS) void ns_search_kernel(
     int n, int m, int c, int tiles_per_cloud, const float *__restrict__ xyz1,
     const int *__restrict__ qsorted,            // (b, n) query indices in Morton order
     const float4 *__restrict__ kp, const float *__restrict__ tb, const float *__restrict__ points2,
-    float *__restrict__ out, long long ldo, float *__restrict__ dist, int *__restrict__ idx, int epi)
+    float *__restrict__ out, long long ldo, float *__restrict__ dist, int *__restrict__ idx, int epi,
+    EpiAffine aff)
 {
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
     // Waves are independent: each stages the tile it visits in its own 1 KB of LDS (no
@@ -319,7 +320,14 @@ __global__ __launch_bounds__(NS_THREADS) void ns_search_kernel(
         const vec_t cc = *reinterpret_cast<const vec_t *>(pb + (size_t)s_i[r * 3 + 2] * c + col);
         vec_t v = a * s_w[r * 3] + bb * s_w[r * 3 + 1] + cc * s_w[r * 3 + 2];   // unfused
         vec_t *op = reinterpret_cast<vec_t *>(out + ((size_t)bi * n + s_q[r]) * ldo + col);
-        if (epi) {                                   // 1: out += v;  2: out = relu(out + v)
+        if (epi >= 3) {                              // 3: affine + relu;  4: affine (EpiAffine)
+            float vv[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) vv[q] = v[q];
+            epi_affine_add<VEC>(aff, (size_t)bi * n + s_q[r], c, col, vv);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) v[q] = epi == 3 ? fmaxf(vv[q], 0.f) : vv[q];
+        } else if (epi) {                            // 1: out += v;  2: out = relu(out + v)
             v = *op + v;
             if (epi == 2) {
 #pragma unroll
@@ -363,7 +371,7 @@ static NsWs ns_carve(void *ws, long long b, long long n, long long m)
 
 static int ns_run(int b, int n, int m, int c, const float *xyz1, const float *xyz2, const float *points2,
                   float *out, long long ldo, float *dist, int *idx, void *ws, size_t ws_bytes, hipStream_t st,
-                  int epi = 0)
+                  int epi = 0, EpiAffine aff = EpiAffine{})
 {
     NsWs w = ns_carve(ws, b, n, m);
     if (!ws || ws_bytes < w.bytes) return PRCNN_WORKSPACE;
@@ -376,15 +384,15 @@ static int ns_run(int b, int n, int m, int c, const float *xyz1, const float *xy
     dim3 grid((n + NS_THREADS - 1) / NS_THREADS, b);
     if (!points2) {
         hipLaunchKernelGGL((ns_search_kernel<1, false>), grid, dim3(NS_THREADS), 0, st, n, m, 0, tiles, xyz1,
-                           w.list_q, w.kp, w.tb, nullptr, nullptr, 0ll, dist, idx, 0);
+                           w.list_q, w.kp, w.tb, nullptr, nullptr, 0ll, dist, idx, 0, aff);
     } else {
         const bool a16 = (((uintptr_t)points2 | (uintptr_t)out) & 15) == 0 && ldo % 4 == 0;
         if (c % 4 == 0 && a16)
             hipLaunchKernelGGL((ns_search_kernel<4, true>), grid, dim3(NS_THREADS), 0, st, n, m, c, tiles, xyz1,
-                               w.list_q, w.kp, w.tb, points2, out, ldo, dist, idx, epi);
+                               w.list_q, w.kp, w.tb, points2, out, ldo, dist, idx, epi, aff);
         else
             hipLaunchKernelGGL((ns_search_kernel<1, true>), grid, dim3(NS_THREADS), 0, st, n, m, c, tiles, xyz1,
-                               w.list_q, w.kp, w.tb, points2, out, ldo, dist, idx, epi);
+                               w.list_q, w.kp, w.tb, points2, out, ldo, dist, idx, epi, aff);
     }
     PRCNN_LAUNCH_CHECK();
     return PRCNN_OK;
@@ -580,14 +588,16 @@ extern "C" int prcnn_three_nn_interpolate_sorted(int b, int n, int m, int c, con
 
 // culled fused search with an accumulate / ReLU epilogue (entry point in interp.hip)
 int prcnn_ns_fused(int b, int n, int m, int c, const float *xyz1, const float *xyz2, const float *points2,
-                   float *out, int64_t ldo, float *dist, int *idx, int epi, void *ws, size_t ws_bytes,
+                   float *out, int64_t ldo, float *dist, int *idx, int epi, const prcnn::EpiAffine *aff,
+                   void *ws, size_t ws_bytes,
                    prcnn_stream_t stream)
 {
     if (b < 0 || n < 0 || m <= 0 || c <= 0 || ldo < c) return PRCNN_BAD_SHAPE;
     if (b == 0 || n == 0) return PRCNN_OK;
     if (!xyz1 || !xyz2 || !points2 || !out) return PRCNN_BAD_SHAPE;
     if (b > 65535) return PRCNN_UNSUPPORTED;
-    return prcnn::ns_run(b, n, m, c, xyz1, xyz2, points2, out, ldo, dist, idx, ws, ws_bytes, to_stream(stream), epi);
+    return prcnn::ns_run(b, n, m, c, xyz1, xyz2, points2, out, ldo, dist, idx, ws, ws_bytes, to_stream(stream), epi,
+                         aff ? *aff : prcnn::EpiAffine{});
 }
 
 extern "C" size_t prcnn_query_ball_point_sorted_workspace_bytes(int b, int n, int m)

@@ -369,6 +369,46 @@ def three_nn_interpolate_add(xyz1, xyz2, points2, out, relu=True):
     return out
 
 
+def three_nn_interpolate_affine_supported(b, n, c1):
+    """The affine epilogue exists in the fused search+interpolation kernels only (many queries)."""
+    return c1 <= 4 and not (FP_TWO_STEP_MAX_QUERIES is not None and b * n <= FP_TWO_STEP_MAX_QUERIES)
+
+
+def three_nn_interpolate_affine(xyz1, xyz2, points2, p1, u, t, relu=True):
+    """act(interpolate(points2) + p1 . u + t) -> (b,n,c) in one launch: the split first FP layer
+    whose points1 half is narrow (p1 (b,n,c1) with c1 <= 4, u (c1,c), t (c); p1 None: t only)."""
+    xyz1 = _dev(xyz1, torch.float32, "three_nn_interpolate_affine xyz1", 3, 3)
+    xyz2 = _dev(xyz2, torch.float32, "three_nn_interpolate_affine xyz2", 3, 3)
+    points2 = _dev(points2, torch.float32, "three_nn_interpolate_affine points2", 3)
+    t = _dev(t, torch.float32, "three_nn_interpolate_affine t", 1)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    c = points2.shape[2]
+    if xyz2.shape[0] != b or points2.shape[0] != b or points2.shape[1] != m or t.shape[0] != c:
+        raise ValueError("three_nn_interpolate_affine expects xyz2 (b,m,3), points2 (b,m,c), t (c)")
+    c1 = 0
+    if p1 is not None:
+        p1 = _dev(p1, torch.float32, "three_nn_interpolate_affine p1", 3)
+        u = _dev(u, torch.float32, "three_nn_interpolate_affine u", 2)
+        c1 = p1.shape[2]
+        if p1.shape[:2] != (b, n) or tuple(u.shape) != (c1, c):
+            raise ValueError("three_nn_interpolate_affine expects p1 (b,n,c1) and u (c1,c)")
+    if not three_nn_interpolate_affine_supported(b, n, c1):
+        raise ValueError("three_nn_interpolate_affine: c1 <= 4 and more than %s queries required" % FP_TWO_STEP_MAX_QUERIES)
+    out = torch.empty((b, n, c), dtype=torch.float32, device=xyz1.device)
+    L = _lib.lib()
+    ws, nb = None, 0
+    if _use_sorted_nn(n, m):
+        nb = L.prcnn_three_nn_sorted_workspace_bytes(b, n, m)
+        ws = torch.empty((nb,), dtype=torch.uint8, device=xyz1.device)
+    _lib.check(_run("three_nn_interpolate", {"tests": b * n * m,
+                                             "bytes": b * (12 * n + 12 * m) + b * n * (16 * c + 4 * c1)},
+                    lambda: L.prcnn_three_nn_interpolate_affine(
+        b, n, m, c, _p(xyz1), _p(xyz2), _p(points2), _p(p1), c1, _p(u) if c1 else None, _p(t), _p(out), c,
+        1 if relu else 0, _p(ws), nb, _stream())), "three_nn_interpolate_affine")
+    return out
+
+
 # ---- shared MLP -------------------------------------------------------------------------
 
 def mlp_layer(x, w, scale, shift, relu=True, pool=1, precision=PRECISION_FP32, out=None, out_col=0):

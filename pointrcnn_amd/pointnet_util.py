@@ -319,11 +319,18 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
         co = mlp[0]
         W, s, t = store.layer('%s/conv_0' % scope, c2 + c1, co, bn)
         y2 = ops.mlp_layer(points2.reshape(b * m, c2), W[:c2], s, store.zeros(co), relu=False, precision=precision)
-        if points1 is not None:
-            x = ops.mlp_layer(points1.reshape(b * n, c1), W[c2:], s, t, relu=False, precision=precision)
+        if ops.three_nn_interpolate_affine_supported(b, n, c1):
+            # narrow points1 (the intensity channel of the last RPN level) or none: its half
+            # (p1 W_b) s + t is evaluated in the interpolation epilogue, never stored
+            name = '%s/conv_0' % scope
+            u = store.derived('__fpu/' + name, lambda: (W[c2:] * s.unsqueeze(0)).contiguous()) if c1 else None
+            x = ops.three_nn_interpolate_affine(xyz1, xyz2, y2.reshape(b, m, co), points1, u, t, relu=True)
         else:
-            x = t.expand(b * n, co).contiguous()
-        ops.three_nn_interpolate_add(xyz1, xyz2, y2.reshape(b, m, co), x.reshape(b, n, co), relu=True)
+            if points1 is not None:
+                x = ops.mlp_layer(points1.reshape(b * n, c1), W[c2:], s, t, relu=False, precision=precision)
+            else:
+                x = t.expand(b * n, co).contiguous()
+            ops.three_nn_interpolate_add(xyz1, xyz2, y2.reshape(b, m, co), x.reshape(b, n, co), relu=True)
         c = co
         for i, co in enumerate(mlp[1:], 1):
             W, s, t = store.layer('%s/conv_%d' % (scope, i), c, co, bn)

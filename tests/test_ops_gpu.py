@@ -308,3 +308,27 @@ def test_ball_query_culled_search_is_identical(cuda):
                 assert torch.equal(i0, i1) and torch.equal(c0, c1)
     finally:
         ops.BQ_SORTED_MIN_TESTS = saved
+
+
+@pytest.mark.parametrize("n,m,c,c1", [(40000, 300, 8, 1), (40000, 100, 8, 3), (36000, 260, 6, 1), (40000, 300, 12, 0)])
+def test_three_nn_interpolate_affine_equals_composition(cuda, n, m, c, c1):
+    """Affine epilogue (split FP layer with a narrow points1) == interpolate, then add p1.u + t, ReLU;
+    culled (m >= 256) and brute-force searches, vector and scalar column paths."""
+    rng = np.random.default_rng(n + m + c)
+    b = 2
+    xyz1 = dev(rng.uniform(-20, 20, (b, n, 3)).astype(np.float32), cuda)
+    xyz2 = dev(rng.uniform(-20, 20, (b, m, 3)).astype(np.float32), cuda)
+    p2 = dev(rng.standard_normal((b, m, c)).astype(np.float32), cuda)
+    t = dev(rng.standard_normal(c).astype(np.float32), cuda)
+    p1 = dev(rng.standard_normal((b, n, c1)).astype(np.float32), cuda) if c1 else None
+    u = dev(rng.standard_normal((c1, c)).astype(np.float32), cuda) if c1 else None
+    assert ops.three_nn_interpolate_affine_supported(b, n, c1)
+    interp = ops.three_nn_interpolate(xyz1, xyz2, p2)
+    lin = interp + t + (p1 @ u if c1 else 0)
+    for relu in (True, False):
+        got = ops.three_nn_interpolate_affine(xyz1, xyz2, p2, p1, u, t, relu=relu)
+        want = torch.relu(lin) if relu else lin
+        assert got.shape == (b, n, c)
+        assert float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    assert not ops.three_nn_interpolate_affine_supported(b, n, 5)
+    assert not ops.three_nn_interpolate_affine_supported(1, 1000, 1)

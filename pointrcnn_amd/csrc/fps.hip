@@ -282,9 +282,13 @@ constexpr int FPR_CELLS = 1 << FPR_KEY_BITS;
 
 __device__ __forceinline__ int wave_min_i32_(int v) { return ~wave_max_i32(~v); }
 
-template <int P2, int NW>
-__global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(int n, int m, const float *__restrict__ dataset,
-                                                          int *__restrict__ idxs)
+// COOP: the workgroup holds slice g of a cloud of more than 16384 points (see fps_coop_kernel
+// below in the file for the exchange protocol: one tagged granule per workgroup and iteration).
+template <int P2, int NW, bool COOP>
+__global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(int n_cloud, int m, const float *__restrict__ dataset,
+                                                          int *__restrict__ idxs, int G, int cloud0,
+                                                          unsigned long long *__restrict__ gran,
+                                                          int *__restrict__ err)
 {
     constexpr int NT = NW * 64;
     constexpr int CAP = NT * 2 * P2;
@@ -295,10 +299,17 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(int n, int m, const
     __shared__ int sbits[3];
     __shared__ int wsum[NW];
     __shared__ unsigned long long slot[3];
+    __shared__ unsigned long long bcast[2];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float *data = dataset + (size_t)blockIdx.x * n * 3;
-    int *out = idxs + (size_t)blockIdx.x * m;
+    const int cloud = COOP ? cloud0 + (int)blockIdx.x / G : (int)blockIdx.x;
+    const int g = COOP ? (int)blockIdx.x % G : 0;
+    const int base = g * CAP;                                  // first point of this slice
+    const int n = min(CAP, n_cloud - base);                    // points of this slice
+    const float *cdata = dataset + (size_t)cloud * n_cloud * 3;   // the cloud (winner coordinates)
+    const float *data = cdata + (size_t)base * 3;              // the slice (local indices)
+    int *out = idxs + (size_t)cloud * m;
+    unsigned long long *cgran = COOP ? gran + (size_t)cloud * 2 * G : nullptr;
 
     // -- grid sort of the cloud (order inside a cell is arbitrary; nothing depends on it) --
     {
@@ -410,10 +421,11 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(int n, int m, const
         for (int u = 0; u < 2; ++u) {
             const int r = ((p * NW + wave) << 7) + u * 64 + lane;
             const bool ok = r < n;
-            const int k = ok ? (int)order[r] : 0;
-            const float x = ok ? data[k * 3 + 0] : 0.f, y = ok ? data[k * 3 + 1] : 0.f, z = ok ? data[k * 3 + 2] : 0.f;
+            const int kl = ok ? (int)order[r] : 0;
+            const float x = ok ? data[kl * 3 + 0] : 0.f, y = ok ? data[kl * 3 + 1] : 0.f, z = ok ? data[kl * 3 + 2] : 0.f;
             px[p][u] = x; py[p][u] = y; pz[p][u] = z;
             td[2 * p + u] = ok ? f2i(1e38f) : f2i(-1.0f);
+            const int k = base + kl;                           // index in the cloud
             key[2 * p + u] = ((k & 511) << 8) | (k >> 9);
             if (ok) {
                 lo[0] = fminf(lo[0], x); hi[0] = fmaxf(hi[0], x);
@@ -456,11 +468,11 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(int n, int m, const
     static_assert(P2 <= 16, "wave_best reduces lanes 0..15");
     unsigned wb_hi, wb_lo;
     wave_best(wb_hi, wb_lo);
-    if (tid == 0) out[0] = 0;
+    if (tid == 0 && g == 0) out[0] = 0;
     int old = 0;                                               // wave-uniform
 
     for (int j = 1; j < m; ++j) {
-        const float x1 = data[old * 3 + 0], y1 = data[old * 3 + 1], z1 = data[old * 3 + 2];
+        const float x1 = cdata[old * 3 + 0], y1 = cdata[old * 3 + 1], z1 = cdata[old * 3 + 2];
         // lower bound of the distance from the sample to the box of bucket `lane`
         const float gx = fmaxf(fmaxf(bx0 - x1, x1 - bx1), 0.f);
         const float gy = fmaxf(fmaxf(by0 - y1, y1 - by1), 0.f);
@@ -501,11 +513,48 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(int n, int m, const
         const int cur = j % 3;
         if (lane == 0) atomicMax(&slot[cur], ((unsigned long long)wb_hi << 32) | wb_lo);
         __syncthreads();
-        const unsigned long long win = slot[cur];
+        unsigned long long win;
+        if constexpr (!COOP) {
+            win = slot[cur];
+        } else {
+            if (wave == 0) {
+                const unsigned long long mine = slot[cur];                  // (value+1 | 0, ~key32)
+                const unsigned tag = (unsigned)j & 0x7fffu;
+                if (lane == 0) {
+                    const unsigned long long v = (mine & 0xffffffff00000000ull) | ((mine & 0x1ffffull) << 15) | tag;
+                    __hip_atomic_store(&cgran[(j & 1) * G + g], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                unsigned long long v = 0ull;
+                int spins = 0;
+                bool timeout = false;
+                for (;;) {
+                    if (lane < G)
+                        v = __hip_atomic_load(&cgran[(j & 1) * G + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool ready = lane >= G || ((unsigned)v & 0x7fffu) == tag;
+                    if (__all(ready)) break;
+                    if (++spins > (1 << 22)) { timeout = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (timeout) {
+                    if (lane == 0) { atomicExch(err, 1); bcast[j & 1] = ~0ull; }
+                } else {
+                    unsigned long long w = lane < G ? (v >> 15) : 0ull;
+#pragma unroll
+                    for (int off = 1; off < 16; off <<= 1) {
+                        const unsigned long long o = __shfl_xor(w, off);
+                        w = o > w ? o : w;
+                    }
+                    if (lane == 0) bcast[j & 1] = w;
+                }
+            }
+            __syncthreads();
+            win = bcast[j & 1];
+            if (win == ~0ull) return;                                    // time-out: leave (uniform)
+        }
         if (tid == 0) slot[(j + 2) % 3] = 0ull;
-        const unsigned k2 = ~(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)win);
+        const unsigned k2 = ~(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)win) & 0x1ffffu;
         old = (int)((k2 >> 8) + ((k2 & 255u) << 9));
-        if (tid == 0) out[j] = old;
+        if (tid == 0 && g == 0) out[j] = old;
     }
 }
 
@@ -560,7 +609,8 @@ extern "C" int prcnn_farthest_point_sample(int b, int n, int m, const float *inp
         if (n <= 16384 && m >= 2 && (pm == 2 || (pm == 1 && n > 4096 && m >= 256))) {
             // 16 waves x 8 buckets; 8 waves x 16 buckets has less fixed cost per iteration but longer
             // update chains per wave: 0.82 vs 0.75 us/iteration measured
-            hipLaunchKernelGGL((fps_pruned_kernel<8, 16>), dim3(b), dim3(1024), 0, st, n, m, inp, out);
+            hipLaunchKernelGGL((fps_pruned_kernel<8, 16, false>), dim3(b), dim3(1024), 0, st, n, m, inp, out, 1, 0,
+                               nullptr, nullptr);
             PRCNN_LAUNCH_CHECK();
             return PRCNN_OK;
         }
@@ -583,7 +633,11 @@ extern "C" int prcnn_farthest_point_sample(int b, int n, int m, const float *inp
     const int per_launch = 256 / G;                   // clouds whose workgroups are co-resident
     for (int c0 = 0; c0 < b; c0 += per_launch) {
         const int nc = b - c0 < per_launch ? b - c0 : per_launch;
-        hipLaunchKernelGGL(fps_coop_kernel, dim3(nc * G), dim3(1024), 0, st, n, m, G, c0, inp, gran, err, out);
+        if (fps_prune_mode() != 0 && m >= 256)      // long runs: pruned slices (in-workgroup sort pays off)
+            hipLaunchKernelGGL((fps_pruned_kernel<8, 16, true>), dim3(nc * G), dim3(1024), 0, st, n, m, inp, out, G,
+                               c0, gran, err);
+        else
+            hipLaunchKernelGGL(fps_coop_kernel, dim3(nc * G), dim3(1024), 0, st, n, m, G, c0, inp, gran, err, out);
         PRCNN_LAUNCH_CHECK();
     }
     return PRCNN_OK;

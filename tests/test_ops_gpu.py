@@ -84,6 +84,15 @@ def test_fps_lds_and_global_paths(cuda):
     assert got[0] == 0 and got.min() >= 0 and got.max() < 131072 and len(set(got.tolist())) == 2048
 
 
+def test_fps_pruned_cooperative_slices(cuda):
+    """n > 16384 with m >= 256: every workgroup prunes its own grid-sorted slice (ragged last
+    slice, 2 / 3 / 8 workgroups per cloud, two clouds per launch)."""
+    for n, m, b in ((20000, 300, 2), (40000, 600, 1), (131072, 260, 1)):
+        pts = np.stack([S.dense_scene(20 + i, n)[:, :3] for i in range(b)])
+        got = npy(ops.farthest_point_sample(m, dev(pts, cuda)))
+        assert np.array_equal(got, O.farthest_point_sample(m, pts)), n
+
+
 def test_fps_single_cu_lds_path_without_workspace(cuda):
     """temp == NULL: clouds of 16385..32768 points run on one CU with the min distances in LDS."""
     from pointrcnn_amd import _lib

@@ -288,7 +288,7 @@ template <int P2, int NW, bool COOP>
 __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(int n_cloud, int m, const float *__restrict__ dataset,
                                                           int *__restrict__ idxs, int G, int cloud0,
                                                           unsigned long long *__restrict__ gran,
-                                                          int *__restrict__ err)
+                                                          int *__restrict__ err, int nc_xcd)
 {
     constexpr int NT = NW * 64;
     constexpr int CAP = NT * 2 * P2;
@@ -302,8 +302,19 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(int n_cloud, int m,
     __shared__ unsigned long long bcast[2];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cloud = COOP ? cloud0 + (int)blockIdx.x / G : (int)blockIdx.x;
-    const int g = COOP ? (int)blockIdx.x % G : 0;
+    // nc_xcd > 0 (COOP): workgroups are dealt to the 8 XCDs round-robin by the dispatcher, so
+    // workgroup w = 8*slot + x is given slice slot%G of cloud x + 8*(slot/G): the G workgroups of
+    // a cloud then share one XCD (one L2) for their per-iteration exchange.  Only a placement
+    // hint: any other dispatch order is still correct.
+    int cl = COOP ? (int)blockIdx.x / G : (int)blockIdx.x;
+    int g = COOP ? (int)blockIdx.x % G : 0;
+    if (COOP && nc_xcd > 0) {
+        const int x = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+        cl = x + 8 * (slot / G);
+        g = slot % G;
+        if (cl >= nc_xcd) return;
+    }
+    const int cloud = COOP ? cloud0 + cl : cl;
     const int base = g * CAP;                                  // first point of this slice
     const int n = min(CAP, n_cloud - base);                    // points of this slice
     const float *cdata = dataset + (size_t)cloud * n_cloud * 3;   // the cloud (winner coordinates)
@@ -533,7 +544,6 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(int n_cloud, int m,
                     const bool ready = lane >= G || ((unsigned)v & 0x7fffu) == tag;
                     if (__all(ready)) break;
                     if (++spins > (1 << 22)) { timeout = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
                 }
                 if (timeout) {
                     if (lane == 0) { atomicExch(err, 1); bcast[j & 1] = ~0ull; }
@@ -610,7 +620,7 @@ extern "C" int prcnn_farthest_point_sample(int b, int n, int m, const float *inp
             // 16 waves x 8 buckets; 8 waves x 16 buckets has less fixed cost per iteration but longer
             // update chains per wave: 0.82 vs 0.75 us/iteration measured
             hipLaunchKernelGGL((fps_pruned_kernel<8, 16, false>), dim3(b), dim3(1024), 0, st, n, m, inp, out, 1, 0,
-                               nullptr, nullptr);
+                               nullptr, nullptr, 0);
             PRCNN_LAUNCH_CHECK();
             return PRCNN_OK;
         }
@@ -633,9 +643,15 @@ extern "C" int prcnn_farthest_point_sample(int b, int n, int m, const float *inp
     const int per_launch = 256 / G;                   // clouds whose workgroups are co-resident
     for (int c0 = 0; c0 < b; c0 += per_launch) {
         const int nc = b - c0 < per_launch ? b - c0 : per_launch;
-        if (fps_prune_mode() != 0 && m >= 256)      // long runs: pruned slices (in-workgroup sort pays off)
-            hipLaunchKernelGGL((fps_pruned_kernel<8, 16, true>), dim3(nc * G), dim3(1024), 0, st, n, m, inp, out, G,
-                               c0, gran, err);
+        if (fps_prune_mode() != 0 && m >= 256) {    // long runs: pruned slices (in-workgroup sort pays off)
+            static const int xcd = getenv("PRCNN_FPS_XCD") ? atoi(getenv("PRCNN_FPS_XCD")) : 1;   // 0: tuning aid
+            if (xcd)
+                hipLaunchKernelGGL((fps_pruned_kernel<8, 16, true>), dim3(8 * G * ((nc + 7) / 8)), dim3(1024), 0, st,
+                                   n, m, inp, out, G, c0, gran, err, nc);
+            else
+                hipLaunchKernelGGL((fps_pruned_kernel<8, 16, true>), dim3(nc * G), dim3(1024), 0, st, n, m, inp, out,
+                                   G, c0, gran, err, 0);
+        }
         else
             hipLaunchKernelGGL(fps_coop_kernel, dim3(nc * G), dim3(1024), 0, st, n, m, G, c0, inp, gran, err, out);
         PRCNN_LAUNCH_CHECK();

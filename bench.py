@@ -142,6 +142,40 @@ def time_fps_dense(device, n=131072, m=16384):
     return {"points": n, "npoint": m, "ms": round(ms, 3), "us_per_iteration": round(1e3 * ms / (m - 1), 4)}
 
 
+def time_frustum(device, store, precision, batch=32, iters=20):
+    """BASELINE configs[1] (secondary number, not `value`): the three Frustum PointNet v2 SA/FP
+    stacks (cls + seg on 1024-point frustums, box net on 512 masked points), batch 32, as one
+    HIP-graph replay per batch."""
+    store = PU.ParamStore(seed=9, device=device)     # own weights: the seg net's scope names are the RPN's
+    fr = torch.as_tensor(S.frustum_batch(1, batch, 1024)).to(device)
+    obj = torch.as_tensor(S.frustum_batch(2, batch, 512, channels=3)).to(device)
+    onehot = torch.zeros((batch, 4), device=device); onehot[:, 1] = 1
+
+    def once():
+        return (stacks.frustum_cls_stack(fr, params=store, precision=precision),
+                stacks.frustum_seg_stack(fr, onehot, params=store, precision=precision),
+                stacks.frustum_box_stack(obj, params=store, precision=precision))
+    st = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(st):
+        once(); once()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st):
+        keepalive = once()
+    with torch.cuda.stream(st):
+        g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            g.replay()
+        e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    del keepalive
+    return {"workload": "Frustum PointNet v2 cls + seg (1024 pts) + box (512 pts) SA/FP stacks, batch %d" % batch,
+            "ms_per_batch": round(ms, 3), "frustums_per_s": round(batch / (ms * 1e-3), 1)}
+
+
 def cpu_baseline(store, seconds_cap=40.0):
     """The CPU oracle (reference CPU path: C++ CPU ops restated + transcribed FPS kernel)
     on ONE 16384-point scene of the same generator, single thread."""
@@ -201,6 +235,9 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="sample each batch's centroids inside its own step instead of one step ahead")
     args = ap.parse_args()
+    if os.environ.get("PRCNN_BENCH_WATCHDOG"):        # debugging aid: dump all stacks and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["PRCNN_BENCH_WATCHDOG"]), exit=True)
 
     rank, world, local = pdist.init_from_env("cuda")
     if world != args.gpus and world > 1:
@@ -395,6 +432,7 @@ def main():
             "nms": {"ms_9000_to_100": round(nms_ms, 4), "kept": nms_keep, "pairs": 9000 * 8999 // 2,
                     "metric": "rotated-NMS ms @9k boxes"},
             "fps_dense": time_fps_dense(device),
+            "frustum": time_frustum(device, store, precision),
             "hbm_copy_gbps": {"value": round(hbm_copy, 1), "what": "torch device-to-device copy of 1 GiB, read+write bytes / time"},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -25,9 +25,14 @@ def init_from_env(device_type="cuda"):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if device_type == "cuda" else "gloo"
+        # PRCNN_DIST_BACKEND=gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks
+        # (ranks then share devices, local rank modulo the device count); RCCL is the product path
+        backend = os.environ.get("PRCNN_DIST_BACKEND", "nccl") if device_type == "cuda" else "gloo"
         if device_type == "cuda":
+            if backend != "nccl":
+                local = local % max(1, torch.cuda.device_count())
             torch.cuda.set_device(local)
+        if backend == "nccl":
             dist.init_process_group(backend=backend, rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local))
         else:

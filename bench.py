@@ -65,36 +65,64 @@ def make_inputs(rank, device, batch):
     return pcs, prop
 
 
-def step(pcs, prop, store, precision, geo=None, centroids=None):
+def detections(prop):
+    """Per-scene rotated NMS of the batch's proposals (2048 -> 100, IoU 0.8) + detection records."""
+    keep, nk = nms_rotate_batched(prop["bev"], prop["scores"], 0.8, pdist.MAX_DET)
+    return pdist.pack_detections(prop["scene_ids"], prop["boxes3d"], prop["scores"], keep, nk)
+
+
+def step(pcs, prop, store, precision, geo=None, centroids=None, geometry=None, rec=None):
     """SA+FP stack on the batch, per-scene rotated NMS of its proposals, detection records."""
     feats, _ = stacks.rpn_sa_fp_stack(pcs, params=store, precision=precision, geometry_stream=geo,
-                                      centroids=centroids)
-    keep, nk = nms_rotate_batched(prop["bev"], prop["scores"], 0.8, pdist.MAX_DET)
-    rec = pdist.pack_detections(prop["scene_ids"], prop["boxes3d"], prop["scores"], keep, nk)
-    return feats, rec
+                                      centroids=centroids, geometry=geometry)
+    return feats, (detections(prop) if rec is None else rec)
 
 
-def pipelined_step(pcs_cur, pcs_next, prop, store, precision, cent_cur, cent_next, side, group=1):
-    """`group` steps of the software-pipelined schedule: the feature phases of the current
-    `group` batches (grouping, MLPs, interpolation, NMS, records) run one after the other on
-    the current stream with the centroids sampled one replay earlier, while ONE strictly
-    serial FPS chain over the clouds of the NEXT `group` batches (group x 16 workgroups) runs
-    on `side` into `cent_next`.  Every batch still gets one complete FPS pass and one complete
-    feature phase; only their pairing is shifted, so the latency-bound sampling (6.3 ms per
-    chain whatever the number of clouds, 16 CUs per batch) never gates full-chip work, and
-    one chain's latency is spread over `group` batches.  Returns one (feats, rec) per batch."""
+def ahead_work(pcs_next, prop, cent_next, geo_next, group):
+    """What runs AHEAD of (and beside) the feature phases: ONE strictly serial FPS chain over the
+    clouds of the next `group` batches into `cent_next`; with `geo_next` also everything else
+    that depends on coordinates only (ball queries of all SA scales, three_nn + weights of all FP
+    levels: stacks.rpn_geometry) into `geo_next`, and the rotated NMS + detection records of the
+    CURRENT batches (independent of the stack).  Returns the records ([None]*group without
+    `geo_next`)."""
+    xyz_next = pcs_next[:, :, 0:3].contiguous()
+    if group > 1:
+        xyz_next = xyz_next.repeat(group, 1, 1)              # synthetic input: the same batch again
+    xs, _ = stacks.sample_centroid_chain(xyz_next, [lv[0] for lv in stacks.RPN_SA])
+    for dst, x in zip(cent_next, xs):
+        dst.copy_(x)
+    if geo_next is None:
+        return [None] * group
+    g_next = stacks.rpn_geometry(xyz_next, xs)
+    for dst, src in zip(stacks.geometry_tensors(geo_next), stacks.geometry_tensors(g_next)):
+        dst.copy_(src)
+    return [detections(prop) for _ in range(group)]
+
+
+def feature_work(pcs_cur, prop, store, precision, cent_cur, geo_cur, group, recs):
+    """The feature phases (grouping, MLPs, interpolation; NMS + records unless `recs` has them) of
+    the current `group` batches with centroids (and geometry) prepared one replay earlier."""
+    b = pcs_cur.shape[0]
+    return [step(pcs_cur, prop, store, precision, centroids=[c[g * b:(g + 1) * b] for c in cent_cur],
+                 geometry=None if geo_cur is None else stacks.geometry_slice(geo_cur, g * b, (g + 1) * b),
+                 rec=recs[g])
+            for g in range(group)]
+
+
+def pipelined_step(pcs_cur, pcs_next, prop, store, precision, cent_cur, cent_next, side, group=1,
+                   geo_cur=None, geo_next=None):
+    """`group` steps of the software-pipelined schedule as ONE unit of work forked over two
+    streams: feature_work of the current `group` batches on the current stream, ahead_work for
+    the next `group` batches on `side`.  Every batch still gets one complete FPS pass and one
+    complete feature phase; only their pairing is shifted, so the latency-bound sampling (one
+    chain costs the same whatever the number of clouds, 16 CUs per batch) never gates full-chip
+    work, and one chain's latency is spread over `group` batches.  Returns one (feats, rec) per
+    batch."""
     cur = torch.cuda.current_stream()
     side.wait_stream(cur)
     with torch.cuda.stream(side):
-        xyz_next = pcs_next[:, :, 0:3].contiguous()
-        if group > 1:
-            xyz_next = xyz_next.repeat(group, 1, 1)          # synthetic input: the same batch again
-        xs, _ = stacks.sample_centroid_chain(xyz_next, [lv[0] for lv in stacks.RPN_SA])
-        for dst, x in zip(cent_next, xs):
-            dst.copy_(x)
-    b = pcs_cur.shape[0]
-    outs = [step(pcs_cur, prop, store, precision, centroids=[c[g * b:(g + 1) * b] for c in cent_cur])
-            for g in range(group)]
+        recs = ahead_work(pcs_next, prop, cent_next, geo_next, group)
+    outs = feature_work(pcs_cur, prop, store, precision, cent_cur, geo_cur, group, recs)
     cur.wait_stream(side)
     return outs
 
@@ -232,6 +260,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="issue every step eagerly instead of replaying HIP graphs")
     ap.add_argument("--fps-group", type=int, default=4,
                     help="batches per graph replay: one FPS chain samples this many upcoming batches at once")
+    ap.add_argument("--geo-ahead", action="store_true",
+                    help="pipelined schedule: answer ball queries / three_nn (+ NMS) on the FPS side stream one "
+                         "replay ahead instead of in line with the feature phase (measured: 6510 vs 6757 scenes/s "
+                         "in line -- the chip is bound by total work / power, not by stream order; kept as an option)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="sample each batch's centroids inside its own step instead of one step ahead")
     args = ap.parse_args()
@@ -254,6 +286,7 @@ def main():
     # One HIP graph of the whole step per stream (the C ABI allocates nothing and never
     # synchronises, so it captures as is); the all-gather stays outside the graph.
     graphs, outs = [], []
+    two_graph = False
     pipelined = not (args.no_graph or args.no_pipeline or args.geo_stream)
     # graphs of ~500 kernel nodes (6 batches) crash inside hipGraphLaunch on this ROCm; 5 is measured safe
     group = min(5, max(1, args.fps_group)) if pipelined else 1
@@ -263,15 +296,43 @@ def main():
         # (r+1)%2.  Units of `group` batches carry the bulk; single-batch units serve the
         # remainder when the step count is not a multiple of `group`.
         sides = [torch.cuda.Stream(device=device) for _ in streams]
+        # --geo-ahead: the ahead work (FPS chain + geometry + NMS) and the feature work
+        # are two graphs per replay unit, launched on the side and the main stream with stream-level
+        # ordering between replays.  The side graph fills set B (centroids + geometry of the next
+        # batches, one flat buffer), the main graph reads set A, and ONE device copy B -> A closes
+        # the replay (~100 MB per 4 batches: 1 % of a replay), so a unit needs one pair of graphs, not
+        # a ping-pong of two.  This ROCm segfaults inside hipGraphLaunch once the live graphs of
+        # the process hold more than ~1600 nodes in total (measured: 1500 run, 1660 and 1740
+        # crash, whatever their shape); this layout holds ~850.
+        two_graph = args.geo_ahead
         for st, side in zip(streams, sides):
             kinds = {}
-            for G in sorted({group, 1}):
+            for G in sorted({group, 1} if (args.steps % group or args.warmup % group) else {group}):
                 with torch.cuda.stream(st):
-                    xs, _ = stacks.sample_centroid_chain(pcs[:, :, 0:3].contiguous().repeat(G, 1, 1),
-                                                         [lv[0] for lv in stacks.RPN_SA])
-                    cents = [[x.clone() for x in xs], [x.clone() for x in xs]]
-                    pipelined_step(pcs, pcs, prop, store, precision, cents[0], cents[1], side, G)   # warm-up
+                    xyz_rep = pcs[:, :, 0:3].contiguous().repeat(G, 1, 1)
+                    xs, _ = stacks.sample_centroid_chain(xyz_rep, [lv[0] for lv in stacks.RPN_SA])
+                    if two_graph:
+                        g0 = stacks.rpn_geometry(xyz_rep, xs)
+                        tens = list(xs) + stacks.geometry_tensors(g0)
+                        flat_a, va = stacks.flat_copy_set(tens)
+                        flat_b, vb = stacks.flat_copy_set(tens)
+                        cents = [va[:len(xs)], vb[:len(xs)]]
+                        gsets = [stacks.geometry_from_tensors(g0, va[len(xs):]),
+                                 stacks.geometry_from_tensors(g0, vb[len(xs):])]
+                    else:
+                        cents = [[x.clone() for x in xs], [x.clone() for x in xs]]
+                        gsets = [None, None]
+                    pipelined_step(pcs, pcs, prop, store, precision, cents[0], cents[1], side, G,
+                                   gsets[0], gsets[1])                                              # warm-up
                 torch.cuda.synchronize()
+                if two_graph:
+                    g_side, g_main = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_side, stream=side):
+                        recs = ahead_work(pcs, prop, cents[1], gsets[1], G)
+                    with torch.cuda.graph(g_main, stream=st):
+                        o = feature_work(pcs, prop, store, precision, cents[0], gsets[0], G, recs)
+                    kinds[G] = ((g_main, g_side, flat_a, flat_b), o)
+                    continue
                 pair, opair = [], []
                 for w in (0, 1):
                     g = torch.cuda.CUDAGraph()
@@ -290,7 +351,7 @@ def main():
                 o = step(pcs, prop, store, precision, geo)
             graphs.append(g); outs.append(o)
 
-    replays = [{group: 0, 1: 0} for _ in streams]
+    replays = [{group: 0, 1: 0} for _ in streams]      # ping-pong position per unit size (single-graph mode)
 
     def run_steps(k, timer=None):
         prev = ops.set_timer(timer)
@@ -299,13 +360,27 @@ def main():
                 units = [group] * (k // group) + [1] * (k % group)
                 for u, G in enumerate(units):
                     j = u % len(streams)
-                    with torch.cuda.stream(streams[j]):
+                    if two_graph:
+                        (g_main, g_side, flat_a, flat_b), o = graphs[j][G]
+                        # side graph r overwrites set B, which the closing copy of replay r-1 read;
+                        # main graph r reads set A, which that copy wrote
+                        sides[j].wait_stream(streams[j])
+                        with torch.cuda.stream(sides[j]):
+                            g_side.replay()
+                    else:
                         w = replays[j][G] & 1
                         replays[j][G] += 1
                         pair, opair = graphs[j][G]
-                        pair[w].replay()
+                        o = opair[w]
+                    with torch.cuda.stream(streams[j]):
+                        if two_graph:
+                            g_main.replay()
+                            streams[j].wait_stream(sides[j])
+                            flat_a.copy_(flat_b)
+                        else:
+                            pair[w].replay()
                         # one collective per replay: the records of its batches travel together
-                        recs = [rec for _, rec in opair[w]]
+                        recs = [rec for _, rec in o]
                         pdist.all_gather_detections(recs[0] if len(recs) == 1 or world == 1 else torch.cat(recs, 0))
                 return
             for i in range(k):
@@ -424,7 +499,8 @@ def main():
                                    (args.batch, NPTS, NPROP, " + RCCL all-gather of detections" if world > 1 else ""),
                        "batch_per_gpu": args.batch, "points": NPTS, "streams": len(streams),
                        "hip_graph": bool(graphs), "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3),
-                       "geometry_streams": bool(args.geo_stream), "fps_one_step_ahead": bool(pipelined), "batches_per_replay": group,
+                       "geometry_streams": bool(args.geo_stream), "fps_one_step_ahead": bool(pipelined),
+                       "geometry_one_replay_ahead": bool(pipelined and args.geo_ahead), "batches_per_replay": group,
                        "kernel_timing": "HIP events around every launch in an eager, single-stream instrumented "
                                         "pass of the same steps after the timed region",
                        "parallelism": "scene-sharded x%d" % world},

@@ -258,6 +258,15 @@ int prcnn_three_interpolate_add(int b, int m, int c, int n, const float *points,
                                 const float *weight, float *out, int64_t ldo, int relu,
                                 prcnn_stream_t stream);
 
+/* prcnn_three_nn_interpolate_affine without the search (additive): idx / weight (b,n,3) come
+ * from prcnn_three_nn[_sorted] + prcnn_fp_weights, e.g. computed ahead of the feature phase on
+ * another stream (they depend on coordinates only).  out[q][:c] = act(three_interpolate(points,
+ * idx, weight)[q] + p1[q][:c1] . u + t); same arithmetic, same bits as the fused entry point. */
+int prcnn_three_interpolate_affine(int b, int m, int c, int n, const float *points, const int *idx,
+                                   const float *weight, const float *p1, int c1, const float *u,
+                                   const float *t, float *out, int64_t ldo, int relu,
+                                   prcnn_stream_t stream);
+
 /* prcnn_query_ball_point_msg with the spatially culled search (additive; identical idx /
  * pts_cnt): points are bucketed and tiled, a wave of four neighbouring centroids visits only
  * tiles within the largest radius, and the per-ball hits are reduced to the nsample smallest

@@ -52,6 +52,7 @@ SIGNATURES = {
                                                _vp, _sz, _vp]),
     "prcnn_three_nn_interpolate_add": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i, _vp, _sz, _vp]),
     "prcnn_three_interpolate_add": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    "prcnn_three_interpolate_affine": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _vp]),
     "prcnn_query_ball_point_sorted_workspace_bytes": (_sz, [_i, _i, _i]),
     "prcnn_query_ball_point_msg_sorted": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "prcnn_selection_sort": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(int m, int c, in
                                                                 const float *__restrict__ points,
                                                                 const int *__restrict__ idx,
                                                                 const float *__restrict__ weight,
-                                                                float *__restrict__ out, long long ldo, int epi)
+                                                                float *__restrict__ out, long long ldo, int epi,
+                                                                EpiAffine aff)
 {
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
     const int cv = c / VEC;
@@ -153,7 +154,14 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(int m, int c, in
         const vec_t cc = *reinterpret_cast<const vec_t *>(pb + (size_t)i3 * c);
         vec_t r = a * w1 + bb * w2 + cc * w3;         // unfused: -ffp-contract=off
         vec_t *op = reinterpret_cast<vec_t *>(out + (size_t)row * ldo + col);
-        if (epi) {                                    // 1: out += r;  2: out = relu(out + r)
+        if (epi >= 3) {                               // 3: affine + relu;  4: affine (EpiAffine)
+            float vv[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) vv[q] = r[q];
+            epi_affine_add<VEC>(aff, (size_t)row, c, col, vv);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) r[q] = epi == 3 ? fmaxf(vv[q], 0.f) : vv[q];
+        } else if (epi) {                             // 1: out += r;  2: out = relu(out + r)
             r = *op + r;
             if (epi == 2) {
 #pragma unroll
@@ -265,7 +273,8 @@ extern "C" int prcnn_fp_weights(int64_t rows, const float *dist, float *weight,
 }
 
 static int launch_interpolate(int b, int m, int c, int n, const float *points, const int *idx,
-                              const float *weight, float *out, int64_t ldo, int epi, prcnn_stream_t stream)
+                              const float *weight, float *out, int64_t ldo, int epi, prcnn_stream_t stream,
+                              prcnn::EpiAffine aff = prcnn::EpiAffine{})
 {
     using namespace prcnn;
     if (b < 0 || m <= 0 || c < 0 || n < 0 || ldo < c) return PRCNN_BAD_SHAPE;   // tf_interpolate.cpp:203,206
@@ -279,13 +288,13 @@ static int launch_interpolate(int b, int m, int c, int n, const float *points, c
         long long blocks = (tv + 255) / 256;
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(three_interpolate_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, m, c,
-                           n, tv, points, idx, weight, out, (long long)ldo, epi);
+                           n, tv, points, idx, weight, out, (long long)ldo, epi, aff);
     } else {
         const long long tv = rows * c;
         long long blocks = (tv + 255) / 256;
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(three_interpolate_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, m, c,
-                           n, tv, points, idx, weight, out, (long long)ldo, epi);
+                           n, tv, points, idx, weight, out, (long long)ldo, epi, aff);
     }
     PRCNN_LAUNCH_CHECK();
     return PRCNN_OK;
@@ -303,6 +312,17 @@ extern "C" int prcnn_three_interpolate_add(int b, int m, int c, int n, const flo
                                            int64_t ldo, int relu, prcnn_stream_t stream)
 {
     return launch_interpolate(b, m, c, n, points, idx, weight, out, ldo, relu ? 2 : 1, stream);
+}
+
+extern "C" int prcnn_three_interpolate_affine(int b, int m, int c, int n, const float *points,
+                                              const int *idx, const float *weight, const float *p1, int c1,
+                                              const float *u, const float *t, float *out, int64_t ldo,
+                                              int relu, prcnn_stream_t stream)
+{
+    if (c1 < 0 || c1 > 4) return PRCNN_UNSUPPORTED;
+    if (!t || (c1 > 0 && (!p1 || !u))) return PRCNN_BAD_SHAPE;
+    prcnn::EpiAffine aff = {p1, u, t, c1};
+    return launch_interpolate(b, m, c, n, points, idx, weight, out, ldo, relu ? 3 : 4, stream, aff);
 }
 
 static int launch_fused_nn(int b, int n, int m, int c, const float *xyz1, const float *xyz2,

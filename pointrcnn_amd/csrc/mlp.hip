@@ -155,6 +155,9 @@ __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     // B: BK x BN elements; thread -> k = tid / (BN/BPT), n-offset
     constexpr int B_PER = BK * BN / MLP_THREADS;     // elements per thread
     constexpr int B_TPR = BN / B_PER;                // threads per k-row
+    constexpr int BV = (B_PER % 4 == 0) ? 4 : ((B_PER % 2 == 0) ? 2 : 1);   // floats per B load (96-wide tiles: 6 = 3 x 2)
+    typedef float bvec_t __attribute__((ext_vector_type(BV)));
+    static_assert(B_PER * B_TPR == BN && B_TPR * BK == MLP_THREADS, "B staging must tile the chunk exactly");
     const int bk = tid / B_TPR, bn = (tid % B_TPR) * B_PER;
     const bool b_vec = (a.cout & 3) == 0 && (((uintptr_t)a.w) & 15) == 0;
 
@@ -181,38 +184,30 @@ __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             for (int v = 0; v < A_PER / 4; ++v)
                 areg[v] = load_a4<GATHER>(a, rs, k0 + ahalf * A_PER + v * 4, a_vec);
         }
-        if (B_PER >= 4 && b_fast && k0 + BK <= a.cin) {
+        if (BV >= 2 && b_fast && k0 + BK <= a.cin) {
             const float *wp = b_base + (size_t)k0 * a.cout;
 #pragma unroll
-            for (int v = 0; v < B_PER / 4; ++v) {
-                const f32x4 t = *reinterpret_cast<const f32x4 *>(wp + v * 4);
-                breg[v * 4 + 0] = t[0]; breg[v * 4 + 1] = t[1];
-                breg[v * 4 + 2] = t[2]; breg[v * 4 + 3] = t[3];
+            for (int v = 0; v < B_PER / BV; ++v) {
+                const bvec_t t = *reinterpret_cast<const bvec_t *>(wp + v * BV);
+#pragma unroll
+                for (int e = 0; e < BV; ++e) breg[v * BV + e] = t[e];
             }
             return;
         }
         const int k = k0 + bk;
         const bool kok = k < a.cin;
         const float *wrow = a.w + (size_t)(kok ? k : 0) * a.cout;
-        if constexpr (B_PER >= 4) {
 #pragma unroll
-            for (int v = 0; v < B_PER / 4; ++v) {
-                const int n = col0 + bn + v * 4;
-                if (kok && b_vec && n + 4 <= a.cout) {
-                    const f32x4 t = *reinterpret_cast<const f32x4 *>(wrow + n);
-                    breg[v * 4 + 0] = t[0]; breg[v * 4 + 1] = t[1];
-                    breg[v * 4 + 2] = t[2]; breg[v * 4 + 3] = t[3];
-                } else {
+        for (int v = 0; v < B_PER / BV; ++v) {
+            const int n = col0 + bn + v * BV;
+            if (BV >= 2 && kok && b_vec && n + BV <= a.cout) {
+                const bvec_t t = *reinterpret_cast<const bvec_t *>(wrow + n);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        breg[v * 4 + e] = (kok && n + e < a.cout) ? wrow[n + e] : 0.f;
-                }
-            }
-        } else {
+                for (int e = 0; e < BV; ++e) breg[v * BV + e] = t[e];
+            } else {
 #pragma unroll
-            for (int e = 0; e < B_PER; ++e) {
-                const int n = col0 + bn + e;
-                breg[e] = (kok && n < a.cout) ? wrow[n] : 0.f;
+                for (int e = 0; e < BV; ++e)
+                    breg[v * BV + e] = (kok && n + e < a.cout) ? wrow[n + e] : 0.f;
             }
         }
     };
@@ -425,7 +420,7 @@ static int launch_mlp(const MlpArgs &a, hipStream_t st)
     const long long wgs128 = rb * ((a.cout + 127) / 128);
     if (a.cout <= 32) bn = 32;
     else if (a.cout <= 64) bn = 64;
-    else if (a.cout <= 96) bn = rb >= 2048 ? 32 : 64;
+    else if (a.cout <= 96) bn = 96;   // one 128 x 96 tile per row block: A is staged once (was 3 x 32: 109 -> ? us at K64 N96)
     else if (wgs128 < 256) bn = rb * ((a.cout + 63) / 64) < 256 ? 32 : 64;
     else bn = 128;      // at 4 waves/SIMD the 128-wide tile wins from one workgroup per CU on (sweep 2)
     if (const char *f = getenv("PRCNN_MLP_BN")) bn = atoi(f);   // tuning aid (32 / 64 / 128)
@@ -438,6 +433,7 @@ static int launch_mlp(const MlpArgs &a, hipStream_t st)
     hipLaunchKernelGGL((mlp_kernel<WM_, WN_, TM_, TN_, GATHER, BF16, KB_>), grid, dim3(MLP_THREADS), 0, st, a)
     if (bn == 32) { if (kb == 16) PRCNN_MLP_LAUNCH(4, 1, 1, 1, 16); else PRCNN_MLP_LAUNCH(4, 1, 1, 1, 32); }
     else if (bn == 64) { if (kb == 16) PRCNN_MLP_LAUNCH(4, 1, 1, 2, 16); else PRCNN_MLP_LAUNCH(4, 1, 1, 2, 32); }
+    else if (bn == 96) { if (kb == 16) PRCNN_MLP_LAUNCH(4, 1, 1, 3, 16); else PRCNN_MLP_LAUNCH(4, 1, 1, 3, 32); }
     else { if (kb == 16) PRCNN_MLP_LAUNCH(2, 2, 2, 2, 16); else PRCNN_MLP_LAUNCH(2, 2, 2, 2, 32); }
 #undef PRCNN_MLP_LAUNCH
     PRCNN_LAUNCH_CHECK();

@@ -90,16 +90,19 @@ __device__ __forceinline__ void chain_store(float *X, const float *sc, const flo
     }
 }
 
-template <int K0P, int C1P, int C2P, int C3P>
+// C1P / C2P: widths of the first two layers padded to the 32-column MFMA tile; K1P / K2P: how
+// many of those columns the NEXT layer reads as its K (16 when the real width is <= 16: the
+// padded columns are zero, so skipping them halves that layer's MFMA steps).
+template <int K0P, int C1P, int C2P, int C3P, int K1P = C1P, int K2P = C2P>
 __global__ __launch_bounds__(CHAIN_THREADS) void sa_chain_kernel(const ChainArgs a)
 {
     constexpr int CMAX = K0P > C1P ? (K0P > C2P ? K0P : C2P) : (C1P > C2P ? C1P : C2P);
     constexpr int XS = CMAX + 4;
-    constexpr int WFL = K0P * C1P + C1P * C2P + C2P * C3P;      // weight floats
+    constexpr int WFL = K0P * C1P + K1P * C2P + K2P * C3P;      // weight floats
     constexpr int VFL = 2 * (C1P + C2P + C3P);                  // scale + shift floats
     __shared__ __attribute__((aligned(16))) float lds[WFL + VFL + 4 * 32 * XS];
-    float *W1 = lds, *W2 = W1 + K0P * C1P, *W3 = W2 + C1P * C2P;
-    float *S1 = W3 + C2P * C3P, *T1 = S1 + C1P, *S2 = T1 + C1P, *T2 = S2 + C2P, *S3 = T2 + C2P,
+    float *W1 = lds, *W2 = W1 + K0P * C1P, *W3 = W2 + K1P * C2P;
+    float *S1 = W3 + K2P * C3P, *T1 = S1 + C1P, *S2 = T1 + C1P, *T2 = S2 + C2P, *S3 = T2 + C2P,
           *T3 = S3 + C3P;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,11 +115,11 @@ __global__ __launch_bounds__(CHAIN_THREADS) void sa_chain_kernel(const ChainArgs
         const int k = e / C1P, o = e - k * C1P;
         W1[e] = (k < k0 && o < a.c1) ? a.w1[k * a.c1 + o] : 0.f;
     }
-    for (int e = tid; e < C1P * C2P; e += CHAIN_THREADS) {
+    for (int e = tid; e < K1P * C2P; e += CHAIN_THREADS) {
         const int k = e / C2P, o = e - k * C2P;
         W2[e] = (k < a.c1 && o < a.c2) ? a.w2[k * a.c2 + o] : 0.f;
     }
-    for (int e = tid; e < C2P * C3P; e += CHAIN_THREADS) {
+    for (int e = tid; e < K2P * C3P; e += CHAIN_THREADS) {
         const int k = e / C3P, o = e - k * C3P;
         W3[e] = (k < a.c2 && o < a.c3) ? a.w3[k * a.c3 + o] : 0.f;
     }
@@ -162,10 +165,10 @@ __global__ __launch_bounds__(CHAIN_THREADS) void sa_chain_kernel(const ChainArgs
         chain_layer<K0P, C1P, XS>(X, W1, li, kh, acc1);
         chain_store<C1P, XS>(X, S1, T1, li, kh, acc1);
         f32x16c acc2[C2P / 32];
-        chain_layer<C1P, C2P, XS>(X, W2, li, kh, acc2);
+        chain_layer<K1P, C2P, XS>(X, W2, li, kh, acc2);
         chain_store<C2P, XS>(X, S2, T2, li, kh, acc2);
         f32x16c acc3[C3P / 32];
-        chain_layer<C2P, C3P, XS>(X, W3, li, kh, acc3);
+        chain_layer<K2P, C3P, XS>(X, W3, li, kh, acc3);
         // ---- scale/shift/ReLU + max over nsample (16: two groups per tile, 32: one) -----------
 #pragma unroll
         for (int j = 0; j < C3P / 32; ++j) {
@@ -197,7 +200,10 @@ static int launch_chain(const ChainArgs &a, hipStream_t st)
     const long long tiles = (a.rows + 31) / 32;
     long long blocks = (tiles + 3) / 4;
     if (blocks > 2048) blocks = 2048;               // persistent-style: weights are loaded once per block
-    hipLaunchKernelGGL((sa_chain_kernel<K0P, 32, 32, C3P>), dim3((unsigned)blocks), dim3(CHAIN_THREADS), 0, st, a);
+    if (a.c1 <= 16 && a.c2 <= 16)
+        hipLaunchKernelGGL((sa_chain_kernel<K0P, 32, 32, C3P, 16, 16>), dim3((unsigned)blocks), dim3(CHAIN_THREADS), 0, st, a);
+    else
+        hipLaunchKernelGGL((sa_chain_kernel<K0P, 32, 32, C3P>), dim3((unsigned)blocks), dim3(CHAIN_THREADS), 0, st, a);
     PRCNN_LAUNCH_CHECK();
     return PRCNN_OK;
 }

@@ -352,12 +352,7 @@ def three_nn_interpolate_add(xyz1, xyz2, points2, out, relu=True):
         # few queries: the fused kernel's interpolation phase (one workgroup per 256 queries)
         # cannot fill the chip; search, then an element-parallel interpolation
         dist, idx = three_nn(xyz1, xyz2)
-        weight = fp_weights(dist)
-        _lib.check(_run("three_interpolate", {"bytes": b * n * (24 + 20 * c)},
-                        lambda: L.prcnn_three_interpolate_add(b, m, c, n, _p(points2), _p(idx), _p(weight), _p(out),
-                                                              out.shape[2], 1 if relu else 0, _stream())),
-                   "three_interpolate_add")
-        return out
+        return three_interpolate_add(points2, idx, fp_weights(dist), out, relu)
     ws, nb = None, 0
     if _use_sorted_nn(n, m):
         nb = L.prcnn_three_nn_sorted_workspace_bytes(b, n, m)
@@ -366,6 +361,52 @@ def three_nn_interpolate_add(xyz1, xyz2, points2, out, relu=True):
                     lambda: L.prcnn_three_nn_interpolate_add(b, n, m, c, _p(xyz1), _p(xyz2), _p(points2), _p(out),
                                                              out.shape[2], 1 if relu else 0, _p(ws), nb, _stream())),
                "three_nn_interpolate_add")
+    return out
+
+
+def three_interpolate_add(points2, idx, weight, out, relu=True):
+    """out[..., :c] = act(out[..., :c] + three_interpolate(points2, idx, weight)) in place, with
+    idx / weight (b,n,3) computed beforehand (three_nn + fp_weights)."""
+    points2 = _dev(points2, torch.float32, "three_interpolate_add points2", 3)
+    idx = _dev(idx, torch.int32, "three_interpolate_add idx", 3, 3)
+    weight = _dev(weight, torch.float32, "three_interpolate_add weight", 3, 3)
+    b, m, c = points2.shape
+    n = idx.shape[1]
+    if idx.shape != weight.shape or idx.shape[0] != b:
+        raise ValueError("three_interpolate_add expects idx/weight of equal shape (b,n,3)")
+    if (not isinstance(out, torch.Tensor) or not out.is_cuda or out.dtype != torch.float32
+            or not out.is_contiguous() or out.dim() != 3 or out.shape[:2] != (b, n) or out.shape[2] < c):
+        raise ValueError("three_interpolate_add: out must be a contiguous (b,n,>=c) float32 GPU tensor")
+    _lib.check(_run("three_interpolate", {"bytes": b * n * (24 + 20 * c)},
+                    lambda: _lib.lib().prcnn_three_interpolate_add(b, m, c, n, _p(points2), _p(idx), _p(weight),
+                                                                   _p(out), out.shape[2], 1 if relu else 0,
+                                                                   _stream())), "three_interpolate_add")
+    return out
+
+
+def three_interpolate_affine(points2, idx, weight, p1, u, t, relu=True):
+    """act(three_interpolate(points2, idx, weight) + p1 . u + t) -> (b,n,c): three_nn_interpolate_affine
+    with the search done beforehand (same arithmetic).  p1 (b,n,c1<=4) or None, u (c1,c), t (c)."""
+    points2 = _dev(points2, torch.float32, "three_interpolate_affine points2", 3)
+    idx = _dev(idx, torch.int32, "three_interpolate_affine idx", 3, 3)
+    weight = _dev(weight, torch.float32, "three_interpolate_affine weight", 3, 3)
+    t = _dev(t, torch.float32, "three_interpolate_affine t", 1)
+    b, m, c = points2.shape
+    n = idx.shape[1]
+    if idx.shape != weight.shape or idx.shape[0] != b or t.shape[0] != c:
+        raise ValueError("three_interpolate_affine expects idx/weight (b,n,3) and t (c)")
+    c1 = 0
+    if p1 is not None:
+        p1 = _dev(p1, torch.float32, "three_interpolate_affine p1", 3)
+        u = _dev(u, torch.float32, "three_interpolate_affine u", 2)
+        c1 = p1.shape[2]
+        if p1.shape[:2] != (b, n) or tuple(u.shape) != (c1, c) or c1 > 4:
+            raise ValueError("three_interpolate_affine expects p1 (b,n,c1<=4) and u (c1,c)")
+    out = torch.empty((b, n, c), dtype=torch.float32, device=points2.device)
+    _lib.check(_run("three_interpolate", {"bytes": b * n * (24 + 16 * c + 4 * c1)},
+                    lambda: _lib.lib().prcnn_three_interpolate_affine(
+        b, m, c, n, _p(points2), _p(idx), _p(weight), _p(p1) if c1 else None, c1, _p(u) if c1 else None, _p(t),
+        _p(out), c, 1 if relu else 0, _stream())), "three_interpolate_affine")
     return out
 
 

@@ -204,7 +204,7 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
 
 def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_list, is_training,
                            bn_decay, scope, bn=True, use_xyz=True, use_nchw=False, params=None,
-                           precision=None, new_xyz=None):
+                           precision=None, new_xyz=None, balls=None):
     """models/pointnet_util.py:155-195 -> new_xyz (b,npoint,3), new_points (b,npoint,sum mlp[k][-1]).
     Channel order inside each scale is [features, xyz_local] (:183)."""
     _check_inference(is_training)
@@ -219,8 +219,11 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
     out = torch.empty((b, npoint, ctot), dtype=torch.float32, device=xyz.device)
     col = 0
     c_feat = 0 if points is None else points.shape[2]
-    # FUSED: one pass over the points answers the ball queries of every scale
-    balls = ops.query_ball_point_msg(radius_list, nsample_list, xyz, new_xyz) if FUSED else None
+    # FUSED: one pass over the points answers the ball queries of every scale; a caller may
+    # pass them in (`balls`: [(idx, pts_cnt)] per scale, e.g. answered on another stream -- they
+    # depend on coordinates only)
+    if balls is None and FUSED:
+        balls = ops.query_ball_point_msg(radius_list, nsample_list, xyz, new_xyz)
     # SA_SPLIT: the first convolution is linear, so its feature half is evaluated once per POINT
     # for all scales together (b*n rows x c_feat x sum c1) instead of once per grouped row
     # (b*m*nsample rows per scale); the grouped layer then gathers those rows and adds the
@@ -300,8 +303,10 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
 
 
 def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True,
-                       params=None, precision=None):
-    """models/pointnet_util.py:198-228 -> (b, ndataset1, mlp[-1])."""
+                       params=None, precision=None, nn=None):
+    """models/pointnet_util.py:198-228 -> (b, ndataset1, mlp[-1]).  `nn` = (idx, weight) of
+    three_nn(xyz1, xyz2) + the inverse-distance weights (:210-214) when the caller has them
+    already (they depend on coordinates only)."""
     _check_inference(is_training)
     store = params if params is not None else get_params()
     precision = PRECISION if precision is None else precision
@@ -319,7 +324,16 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
         co = mlp[0]
         W, s, t = store.layer('%s/conv_0' % scope, c2 + c1, co, bn)
         y2 = ops.mlp_layer(points2.reshape(b * m, c2), W[:c2], s, store.zeros(co), relu=False, precision=precision)
-        if ops.three_nn_interpolate_affine_supported(b, n, c1):
+        if nn is not None:
+            idx, weight = nn
+            if c1 <= 4:
+                name = '%s/conv_0' % scope
+                u = store.derived('__fpu/' + name, lambda: (W[c2:] * s.unsqueeze(0)).contiguous()) if c1 else None
+                x = ops.three_interpolate_affine(y2.reshape(b, m, co), idx, weight, points1, u, t, relu=True)
+            else:
+                x = ops.mlp_layer(points1.reshape(b * n, c1), W[c2:], s, t, relu=False, precision=precision)
+                ops.three_interpolate_add(y2.reshape(b, m, co), idx, weight, x.reshape(b, n, co), relu=True)
+        elif ops.three_nn_interpolate_affine_supported(b, n, c1):
             # narrow points1 (the intensity channel of the last RPN level) or none: its half
             # (p1 W_b) s + t is evaluated in the interpolation epilogue, never stored
             name = '%s/conv_0' % scope
@@ -337,7 +351,11 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
             x = ops.mlp_layer(x, W, s, t, relu=True, precision=precision)
             c = co
         return x.reshape(b, n, mlp[-1])
-    if FUSED:
+    if nn is not None:
+        interpolated_points = ops.three_interpolate(points2, nn[0], nn[1])
+        new_points1 = (torch.cat([interpolated_points, points1], dim=2)
+                       if points1 is not None else interpolated_points)
+    elif FUSED:
         c1 = 0 if points1 is None else points1.shape[2]
         new_points1 = torch.empty((b, n, c2 + c1), dtype=torch.float32, device=xyz1.device)
         ops.three_nn_interpolate(xyz1, xyz2, points2, out=new_points1)

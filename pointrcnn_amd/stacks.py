@@ -47,8 +47,70 @@ def sample_centroid_chain(l0_xyz, npoints, stream=None):
     return xs, evs
 
 
+def rpn_geometry(l0_xyz, centroids):
+    """Everything in the RPN stack that depends on coordinates only, given the four levels'
+    centroids: the ball-query answers of every SA scale and, per FP level, three_nn + the
+    inverse-distance weights.  Like the FPS chain it can run ahead of (and beside) the feature
+    phase.  Returns {"balls": [[(idx, pts_cnt)] per scale] per SA level,
+                     "nn": [(idx, weight)] per FP level in call order (fa_layer2..5)}."""
+    from . import ops
+    xyzs = [l0_xyz] + list(centroids)
+    balls = [ops.query_ball_point_msg(radii, nsamples, xyzs[li], xyzs[li + 1])
+             for li, (_, radii, nsamples, _) in enumerate(RPN_SA)]
+    nn = []
+    for lo in (3, 2, 1, 0):
+        dist, idx = ops.three_nn(xyzs[lo], xyzs[lo + 1])
+        nn.append((idx, ops.fp_weights(dist)))
+    return {"balls": balls, "nn": nn}
+
+
+def geometry_tensors(geo):
+    """Flat list of the tensors of an rpn_geometry() result (fixed order)."""
+    out = []
+    for level in geo["balls"]:
+        for idx, cnt in level:
+            out += [idx, cnt]
+    for idx, w in geo["nn"]:
+        out += [idx, w]
+    return out
+
+
+def geometry_from_tensors(like, tensors):
+    """Inverse of geometry_tensors: the structure of `like` over the flat list `tensors`."""
+    it = iter(tensors)
+    return {"balls": [[(next(it), next(it)) for _ in level] for level in like["balls"]],
+            "nn": [(next(it), next(it)) for _ in like["nn"]]}
+
+
+def flat_copy_set(tensors):
+    """Copies of `tensors` laid out in ONE flat byte buffer (256-byte aligned pieces): returns
+    (flat, views).  Two such sets of equal layout are copied into one another with one copy."""
+    offs, o = [], 0
+    for t in tensors:
+        offs.append(o)
+        o += (t.numel() * t.element_size() + 255) // 256 * 256
+    flat = torch.empty(max(o, 256), dtype=torch.uint8, device=tensors[0].device)
+    views = []
+    for off, t in zip(offs, tensors):
+        v = flat[off:off + t.numel() * t.element_size()].view(t.dtype).view(t.shape)
+        v.copy_(t)
+        views.append(v)
+    return flat, views
+
+
+def geometry_clone(geo):
+    return {"balls": [[(idx.clone(), cnt.clone()) for idx, cnt in level] for level in geo["balls"]],
+            "nn": [(idx.clone(), w.clone()) for idx, w in geo["nn"]]}
+
+
+def geometry_slice(geo, lo, hi):
+    """The clouds [lo, hi) of a batched rpn_geometry() result (views)."""
+    return {"balls": [[(idx[lo:hi], cnt[lo:hi]) for idx, cnt in level] for level in geo["balls"]],
+            "nn": [(idx[lo:hi], w[lo:hi]) for idx, w in geo["nn"]]}
+
+
 def rpn_sa_fp_stack(point_cloud, params=None, precision=None, is_training=False, bn_decay=None,
-                    geometry_stream=None, centroids=None):
+                    geometry_stream=None, centroids=None, geometry=None):
     """point_cloud (B,N,4) -> per-point features (B,N,128); also returns the level xyz/feature lists.
     With `geometry_stream` the FPS chain of all four levels runs on that stream, overlapped
     with the grouping / MLP work of the main stream (same results)."""
@@ -67,19 +129,21 @@ def rpn_sa_fp_stack(point_cloud, params=None, precision=None, is_training=False,
             torch.cuda.current_stream().wait_event(evs[li])
         x, f = pointnet_sa_module_msg(xyzs[-1], feats[-1], npoint, radii, nsamples, mlps, is_training,
                                       bn_decay, scope='layer%d' % (li + 1), bn=True, params=params,
-                                      precision=precision, new_xyz=None if pre is None else pre[li])
+                                      precision=precision, new_xyz=None if pre is None else pre[li],
+                                      balls=None if geometry is None else geometry["balls"][li])
         xyzs.append(x)
         feats.append(f)
+    nn = [None] * 4 if geometry is None else geometry["nn"]
     l3 = pointnet_fp_module(xyzs[3], xyzs[4], feats[3], feats[4], RPN_FP[0], is_training, bn_decay,
-                            scope='fa_layer2', bn=True, params=params, precision=precision)
+                            scope='fa_layer2', bn=True, params=params, precision=precision, nn=nn[0])
     l2 = pointnet_fp_module(xyzs[2], xyzs[3], feats[2], l3, RPN_FP[1], is_training, bn_decay,
-                            scope='fa_layer3', bn=True, params=params, precision=precision)
+                            scope='fa_layer3', bn=True, params=params, precision=precision, nn=nn[1])
     l1 = pointnet_fp_module(xyzs[1], xyzs[2], feats[1], l2, RPN_FP[2], is_training, bn_decay,
-                            scope='fa_layer4', bn=True, params=params, precision=precision)
+                            scope='fa_layer4', bn=True, params=params, precision=precision, nn=nn[2])
     # concat([l0_xyz, l0_points]) (models/rpn.py:191) is the input cloud itself
     p1 = point_cloud.contiguous()
     l0 = pointnet_fp_module(l0_xyz, xyzs[1], p1, l1, RPN_FP[3], is_training, bn_decay,
-                            scope='fa_layer5', bn=True, params=params, precision=precision)
+                            scope='fa_layer5', bn=True, params=params, precision=precision, nn=nn[3])
     return l0, {"xyz": xyzs, "sa_feats": feats, "fp_feats": [l3, l2, l1, l0]}
 
 

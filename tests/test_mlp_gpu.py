@@ -259,6 +259,49 @@ def test_rpn_stack_runs_and_fused_equals_unfused(cuda):
     assert float(np.abs(npy(out3) - ref).max()) <= 5e-2 * float(np.abs(ref).max())   # 8 layers deep in bf16
 
 
+@pytest.mark.parametrize("split", [True, False])
+def test_rpn_stack_with_precomputed_geometry_is_identical(cuda, split):
+    """Centroids, ball queries and three_nn + weights computed beforehand (stacks.rpn_geometry, on a
+    batch of 5 clouds -- above ops.FP_TWO_STEP_MAX_QUERIES at the last level, so the in-line stack
+    takes the fused affine kernel there -- consumed cloud by cloud) give bit-identical features;
+    the search-free affine interpolation equals the fused search + interpolation kernel."""
+    pc = dev(S.kitti_batch(50, 5), cuda)
+    store = PU.ParamStore(seed=7, device=cuda, randomize_bn=True)
+    PU.FP_SPLIT = split
+    try:
+        ref, aux = stacks.rpn_sa_fp_stack(pc, params=store)
+        xyz = pc[:, :, 0:3].contiguous()
+        cents, _ = stacks.sample_centroid_chain(xyz, [lv[0] for lv in stacks.RPN_SA])
+        geo = stacks.rpn_geometry(xyz, cents)
+        assert len(stacks.geometry_tensors(geo)) == 2 * 8 + 2 * 4
+        both = stacks.geometry_clone(geo)
+        for i in (0, 4):
+            out, _ = stacks.rpn_sa_fp_stack(pc[i:i + 1], params=store, centroids=[c[i:i + 1] for c in cents],
+                                            geometry=stacks.geometry_slice(both, i, i + 1))
+            assert torch.equal(out, ref[i:i + 1])
+    finally:
+        PU.FP_SPLIT = True
+    # the search-free affine epilogue on its own: p1 with 1 and 4 channels, and none
+    b, n, m, c = 2, 5000, 700, 64
+    g = torch.Generator(device='cpu').manual_seed(3)
+    x1 = torch.rand((b, n, 3), generator=g).to(cuda); x2 = torch.rand((b, m, 3), generator=g).to(cuda)
+    p2 = torch.randn((b, m, c), generator=g).to(cuda); t = torch.randn((c,), generator=g).to(cuda)
+    dist, idx = ops.three_nn(x1, x2)
+    w = ops.fp_weights(dist)
+    for c1 in (0, 1, 4):
+        p1 = torch.randn((b, n, c1), generator=g).to(cuda) if c1 else None
+        u = torch.randn((c1, c), generator=g).to(cuda) if c1 else None
+        got = ops.three_interpolate_affine(p2, idx, w, p1, u, t, relu=True)
+        want = ops.three_interpolate(p2, idx, w) + t
+        if c1:
+            # epilogue order: t + p1[0] u[0] + p1[1] u[1] + ... (unfused), then added to the interpolation
+            acc = t.expand(b, n, c).clone()
+            for k in range(c1):
+                acc = acc + p1[:, :, k:k + 1] * u[k].view(1, 1, c)
+            want = ops.three_interpolate(p2, idx, w) + acc
+        assert torch.equal(got, torch.relu(want))
+
+
 def test_frustum_stacks_run(cuda):
     store = PU.ParamStore(seed=9, device=cuda)
     fr = dev(S.frustum_batch(1, 32, 1024), cuda)

@@ -381,7 +381,7 @@ def main():
                             pair[w].replay()
                         # one collective per replay: the records of its batches travel together
                         recs = [rec for _, rec in o]
-                        pdist.all_gather_detections(recs[0] if len(recs) == 1 or world == 1 else torch.cat(recs, 0))
+                        pdist.all_gather_detections(recs[0] if len(recs) == 1 or not dist.is_initialized() else torch.cat(recs, 0))
                 return
             for i in range(k):
                 j = i % len(streams)
@@ -397,7 +397,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -465,7 +465,7 @@ def main():
                 ("mlp_layer", "rows65536 K608 N256 pool1"): "mlp_kernel<2, 2, 2, 2, false, false, 16> grid_threads=262144",
                 ("mlp_layer", "rows262144 K260 N128 pool1"): "mlp_kernel<2, 2, 2, 2, false, false, 16> grid_threads=524288",
                 ("mlp_layer", "rows524288 K96 N128 pool32"): "mlp_kernel<2, 2, 2, 2, false, false, 16> grid_threads=1048576",
-                ("sa_chain", "rows2097152 K4 N32-32-64 pool32"): "sa_chain_kernel<4, 32, 32, 64>",
+                ("sa_chain", "rows2097152 K4 N32-32-64 pool32"): "sa_chain_kernel<4, 32, 32, 64, 32, 32>",
             }
             pk = pmc_keys.get((best["kernel"], best["shape"]))
             if pk and precision == 0 and args.batch == BATCH and os.path.exists(pmc_path):
@@ -514,7 +514,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(store)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -7,7 +7,9 @@ ROCm; "gloo" for CPU tests).  Record layout (float32, RECORD_LEN values):
     [scene_id, n_keep, MAX_DET x (x, y, z, l, h, w, ry, score)]
 ~3.2 KB per scene: the collective is latency-bound, one all-gather per batch is enough.
 """
+import contextlib
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -16,13 +18,31 @@ MAX_DET = 100
 RECORD_LEN = 2 + MAX_DET * 8
 
 
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """RCCL prints a version banner on file descriptor 1 when a communicator is created; callers
+    (bench.py) promise ONE JSON line on stdout, so the group is formed with fd 1 pointed at fd 2."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def init_from_env(device_type="cuda"):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun).
     Returns (rank, world_size, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # PRCNN_DIST_FORCE=1: form the (RCCL) group even for one rank, so that a 1-GPU box exercises
+    # the collective exactly as the N>1 job issues it
+    force = os.environ.get("PRCNN_DIST_FORCE") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         # PRCNN_DIST_BACKEND=gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks
@@ -32,11 +52,15 @@ def init_from_env(device_type="cuda"):
             if backend != "nccl":
                 local = local % max(1, torch.cuda.device_count())
             torch.cuda.set_device(local)
-        if backend == "nccl":
-            dist.init_process_group(backend=backend, rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        with _stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local))
+                # create the communicator now (not inside the first timed collective)
+                dist.barrier(device_ids=[local])
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
@@ -80,8 +104,8 @@ def pack_detections(scene_ids, boxes3d, scores, keep, n_keep):
 
 def all_gather_detections(records):
     """records (S_local, RECORD_LEN) -> (world*S_local, RECORD_LEN) ordered by scene id.
-    One all-gather; with world == 1 (or no process group) it is the identity."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    One all-gather; without a process group it is the identity."""
+    if not dist.is_initialized():
         return records
     world = dist.get_world_size()
     flat = records.contiguous().reshape(-1)

@@ -193,6 +193,21 @@ int prcnn_sa_group_add_layer(int b, int n, int m, int nsample, const float *xyz,
                              const float *shift, int relu, int pool, int precision, float *out,
                              int64_t ldo, prcnn_stream_t stream);
 
+/* A whole hoisted scale in one launch (additive): layer 1 as in prcnn_sa_group_add_layer (table
+ * rows gathered by idx + the 3-column product with the relative coordinates, folded BN, ReLU),
+ * then two more 1x1 convolutions (+ folded BN + ReLU) on the matrix cores and the max over
+ * nsample -- the activations between the layers never leave the CU (models/pointnet_util.py:
+ * 177-192 for one radius).  c1 <= 64, c2 <= 96, c3 <= 128, nsample 16 or 32, fp32; other shapes:
+ * PRCNN_UNSUPPORTED (use the per-layer entry points).  table (b*n, ldt) holds this scale's c1
+ * columns at `table`; w_xyz (3,c1); out rows (b*m) at out + r*ldo. */
+int prcnn_sa_group_add_mlp2_pool(int b, int n, int m, int nsample, const float *xyz,
+                                 const float *new_xyz, const int *idx, const float *table,
+                                 int64_t ldt, int c1, int c2, int c3, const float *w_xyz,
+                                 const float *s1, const float *t1, const float *w2,
+                                 const float *s2, const float *t2, const float *w3,
+                                 const float *s3, const float *t3, float *out, int64_t ldo,
+                                 prcnn_stream_t stream);
+
 /* A whole set-abstraction scale in one launch for NARROW layers: grouping + three shared-MLP
  * layers + max over nsample (pointnet_util.py:177-192 for one radius; :43-53,116-126 for
  * SSG), fp32 matrix cores, no intermediate activation in HBM.  Serves c+3 <= 8, c1,c2 <= 32,

@@ -40,6 +40,8 @@ SIGNATURES = {
     "prcnn_mlp_layer": (_i, [_i64, _i, _i, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp]),
     "prcnn_sa_group_add_layer": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _i, _i, _i,
                                       _vp, _i64, _vp]),
+    "prcnn_sa_group_add_mlp2_pool": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i] + [_vp] * 9 +
+                                     [_vp, _i64, _vp]),
     "prcnn_sa_group_mlp_layer": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp,
                                       _i, _i, _i, _vp, _i64, _vp]),
     "prcnn_sa_group_mlp3_pool": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i] + [_vp] * 9 +

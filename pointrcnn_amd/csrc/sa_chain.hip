@@ -16,6 +16,7 @@
 // Physical k of MFMA step s / lane-half h is h*KS+s (KS = K/2): a lane's A operands of a
 // whole layer are KS contiguous floats of its row (ds_read_b128 / b64), rows padded by 4
 // words (conflict-free), B is read as W[h*KS+s][col] (consecutive lanes, conflict-free).
+#include <stdlib.h>
 #include "common.h"
 
 namespace prcnn {
@@ -194,6 +195,178 @@ __global__ __launch_bounds__(CHAIN_THREADS) void sa_chain_kernel(const ChainArgs
     }
 }
 
+// ---- hoisted first layer + two MFMA layers + max-pool (wider scales) -----------------------
+// For scales whose first convolution has been hoisted out of the grouping (a per-point table
+// T = feats W_f for all scales, see prcnn_sa_group_add_layer): layer 1 is a gather of table rows
+// plus the 3-column product with the relative coordinates, evaluated on the VALU straight into
+// the wave's LDS tile; layers 2 and 3 run on the matrix cores as above and the max over nsample
+// closes the tile.  The three launches this replaces are bound by writing and re-reading the
+// (rows x 64..96) activations through HBM (K64 N96 at batch 16: 335 MB in 97 us); here nothing
+// but the pooled result leaves the CU.  Serves c1 <= 64, c2 <= 64 or 96, c3 <= 128, nsample 16/32
+// (the second RPN level, models/rpn.py:170-173).
+struct Chain2Args {
+    long long rows;            // b*m*nsample
+    int n, m, ns;
+    const float *xyz, *new_xyz;
+    const int *idx;
+    const float *table;        // (b*n, ldt): hoisted feature half of layer 1 (this scale's columns)
+    long long ldt;
+    int c1, c2, c3;
+    const float *wx, *s1, *t1; // (3, c1) xyz rows of the first layer's weights, folded BN
+    const float *w2, *s2, *t2, *w3, *s3, *t3;
+    float *out;
+    long long ldo;
+};
+
+template <int C2P, int NW>
+__global__ __launch_bounds__(NW * 64) void sa_chain2_kernel(const Chain2Args a)
+{
+    constexpr int C1P = 64, C3P = 128;
+    constexpr int XS = (C1P > C2P ? C1P : C2P) + 4;
+    constexpr int NT = NW * 64;
+    __shared__ __attribute__((aligned(16))) float lds[C1P * C2P + C2P * C3P + 5 * C1P + 2 * C2P + 2 * C3P + NW * 32 * XS];
+    float *W2 = lds, *W3 = W2 + C1P * C2P;
+    float *WX = W3 + C2P * C3P;                 // [3][C1P]
+    float *S1 = WX + 3 * C1P, *T1 = S1 + C1P, *S2 = T1 + C1P, *T2 = S2 + C2P, *S3 = T2 + C2P, *T3 = S3 + C3P;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kh = lane >> 5;
+    float *X = T3 + C3P + wave * 32 * XS;
+    __shared__ int next_tile;
+    if (tid == 0) next_tile = 0;
+
+    for (int e = tid; e < C1P * C2P; e += NT) {
+        const int k = e / C2P, o = e - k * C2P;
+        W2[e] = (k < a.c1 && o < a.c2) ? a.w2[k * a.c2 + o] : 0.f;
+    }
+    for (int e = tid; e < C2P * C3P; e += NT) {
+        const int k = e / C3P, o = e - k * C3P;
+        W3[e] = (k < a.c2 && o < a.c3) ? a.w3[k * a.c3 + o] : 0.f;
+    }
+    for (int e = tid; e < 3 * C1P; e += NT) {
+        const int k = e / C1P, o = e - k * C1P;
+        WX[e] = o < a.c1 ? a.wx[k * a.c1 + o] : 0.f;
+    }
+    for (int e = tid; e < C1P; e += NT) { S1[e] = e < a.c1 ? a.s1[e] : 0.f; T1[e] = e < a.c1 ? a.t1[e] : 0.f; }
+    for (int e = tid; e < C2P; e += NT) { S2[e] = e < a.c2 ? a.s2[e] : 0.f; T2[e] = e < a.c2 ? a.t2[e] : 0.f; }
+    for (int e = tid; e < C3P; e += NT) { S3[e] = e < a.c3 ? a.s3[e] : 0.f; T3[e] = e < a.c3 ? a.t3[e] : 0.f; }
+    __syncthreads();
+
+    // this lane's 4 columns of layer 1 (fixed for the whole kernel)
+    const int pc = (lane & 15) * 4;
+    float wx0[4], wx1[4], wx2[4], sc1[4], sh1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        wx0[q] = WX[pc + q]; wx1[q] = WX[C1P + pc + q]; wx2[q] = WX[2 * C1P + pc + q];
+        sc1[q] = S1[pc + q]; sh1[q] = T1[pc + q];
+    }
+    const bool tvec = (a.ldt & 3) == 0 && (((uintptr_t)a.table) & 15) == 0 && (a.c1 & 3) == 0;
+
+    // One workgroup per CU (the weights fill most of its LDS) owns a contiguous run of tiles; its
+    // waves take them one by one from an LDS counter, so a wave that has a SIMD to itself (NW not
+    // a multiple of 4) simply takes more of them.
+    const long long tiles = (a.rows + 31) / 32;
+    const long long per = (tiles + gridDim.x - 1) / gridDim.x;
+    const long long t_begin = (long long)blockIdx.x * per;
+    const long long t_end = t_begin + per < tiles ? t_begin + per : tiles;
+    // Layer-1 inputs of a tile are fetched one tile ahead into registers (the table rows come from
+    // L2 / HBM: with one workgroup per CU nothing else would hide that latency).
+    struct Pre {
+        f32x4c tb[8];
+        float rx[8], ry[8], rz[8];
+        unsigned ok;             // bit it: the row of pass `it` exists
+        long long t;             // tile, -1 = none left
+    };
+    auto grab = [&]() -> long long {
+        int tl = 0;
+        if (lane == 0) tl = atomicAdd(&next_tile, 1);
+        const long long t = t_begin + __builtin_amdgcn_readfirstlane(tl);
+        return t < t_end ? t : -1;
+    };
+    auto fetch = [&](Pre &p) {
+        p.t = grab();
+        p.ok = 0;
+        if (p.t < 0) return;
+        const long long row0 = p.t * 32;
+        // lane l < 32 resolves row row0+l (point row, relative coordinates)
+        long long pt = -1;
+        float dx = 0.f, dy = 0.f, dz = 0.f;
+        if (lane < 32 && row0 + lane < a.rows) {
+            const long long r = row0 + lane;
+            const long long bi = r / ((long long)a.m * a.ns);
+            pt = bi * a.n + a.idx[r];
+            const long long ci = r / a.ns;
+            dx = a.xyz[pt * 3 + 0] - a.new_xyz[ci * 3 + 0];
+            dy = a.xyz[pt * 3 + 1] - a.new_xyz[ci * 3 + 1];
+            dz = a.xyz[pt * 3 + 2] - a.new_xyz[ci * 3 + 2];
+        }
+        const int ptlo = (int)pt, pthi = (int)(pt >> 32);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {                 // 4 rows x 64 columns per pass
+            const int r = it * 4 + (lane >> 4);
+            const long long rp = ((long long)__shfl(pthi, r) << 32) | (unsigned)__shfl(ptlo, r);
+            p.rx[it] = __shfl(dx, r); p.ry[it] = __shfl(dy, r); p.rz[it] = __shfl(dz, r);
+            p.tb[it] = f32x4c{0.f, 0.f, 0.f, 0.f};
+            if (rp >= 0 && pc < a.c1) {
+                p.ok |= 1u << it;
+                const float *src = a.table + rp * a.ldt + pc;
+                if (tvec) p.tb[it] = *reinterpret_cast<const f32x4c *>(src);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) p.tb[it][q] = pc + q < a.c1 ? src[q] : 0.f;
+                }
+            }
+        }
+    };
+    Pre cur;
+    fetch(cur);
+    while (cur.t >= 0) {
+        const long long row0 = cur.t * 32;
+        // ---- layer 1 on the VALU, straight into the wave's tile ---------------------------------
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = it * 4 + (lane >> 4);
+            f32x4c v = {0.f, 0.f, 0.f, 0.f};
+            if (cur.ok & (1u << it)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float xw = __builtin_fmaf(cur.rz[it], wx2[q], __builtin_fmaf(cur.ry[it], wx1[q], cur.rx[it] * wx0[q]));
+                    v[q] = fmaxf((cur.tb[it][q] + xw) * sc1[q] + sh1[q], 0.f);
+                }
+            }
+            *reinterpret_cast<f32x4c *>(X + r * XS + pc) = v;
+        }
+        fetch(cur);              // next tile's loads fly while the matrix cores work on this one
+        // ---- layers 2 and 3 on the matrix cores (wave-private tile, no barrier) -----------------
+        f32x16c acc2[C2P / 32];
+        chain_layer<C1P, C2P, XS>(X, W2, li, kh, acc2);
+        chain_store<C2P, XS>(X, S2, T2, li, kh, acc2);
+        f32x16c acc3[C3P / 32];
+        chain_layer<C2P, C3P, XS>(X, W3, li, kh, acc3);
+#pragma unroll
+        for (int j = 0; j < C3P / 32; ++j) {
+            const int col = j * 32 + li;
+            const float sc = S3[col], sh = T3[col];
+            float g0 = 0.f, g1 = 0.f;                 // ReLU output is >= 0
+#pragma unroll
+            for (int r = 0; r < 8; ++r) g0 = fmaxf(g0, fmaxf(acc3[j][r] * sc + sh, 0.f));
+#pragma unroll
+            for (int r = 8; r < 16; ++r) g1 = fmaxf(g1, fmaxf(acc3[j][r] * sc + sh, 0.f));
+            g0 = fmaxf(g0, __shfl_xor(g0, 32));
+            g1 = fmaxf(g1, __shfl_xor(g1, 32));
+            if (kh == 0 && col < a.c3) {
+                if (a.ns == 16) {
+                    const long long o0 = row0 / 16;
+                    if (row0 < a.rows) a.out[o0 * a.ldo + col] = g0;
+                    if (row0 + 16 < a.rows) a.out[(o0 + 1) * a.ldo + col] = g1;
+                } else {
+                    if (row0 < a.rows) a.out[(row0 / 32) * a.ldo + col] = fmaxf(g0, g1);
+                }
+            }
+        }
+    }
+}
+
 template <int K0P, int C3P>
 static int launch_chain(const ChainArgs &a, hipStream_t st)
 {
@@ -239,4 +412,51 @@ extern "C" int prcnn_sa_group_mlp3_pool(int b, int n, int m, int nsample, int c,
     if (c3 <= 32) return k4 ? launch_chain<4, 32>(a, st) : launch_chain<8, 32>(a, st);
     if (c3 <= 64) return k4 ? launch_chain<4, 64>(a, st) : launch_chain<8, 64>(a, st);
     return k4 ? launch_chain<4, 128>(a, st) : launch_chain<8, 128>(a, st);
+}
+
+extern "C" int prcnn_sa_group_add_mlp2_pool(int b, int n, int m, int nsample, const float *xyz,
+                                            const float *new_xyz, const int *idx, const float *table,
+                                            int64_t ldt, int c1, int c2, int c3, const float *w_xyz,
+                                            const float *s1, const float *t1, const float *w2,
+                                            const float *s2, const float *t2, const float *w3,
+                                            const float *s3, const float *t3, float *out, int64_t ldo,
+                                            prcnn_stream_t stream)
+{
+    using namespace prcnn;
+    if (b < 0 || n <= 0 || m < 0 || nsample <= 0 || c1 <= 0 || c2 <= 0 || c3 <= 0) return PRCNN_BAD_SHAPE;
+    if (nsample != 16 && nsample != 32) return PRCNN_UNSUPPORTED;
+    if (c1 > 64 || c2 > 96 || c3 > 128) return PRCNN_UNSUPPORTED;
+    if (ldo < c3 || ldt < c1) return PRCNN_BAD_SHAPE;
+    const long long rows = (long long)b * m * nsample;
+    if (rows == 0) return PRCNN_OK;
+    if (!xyz || !new_xyz || !idx || !table || !out) return PRCNN_BAD_SHAPE;
+    if (!w_xyz || !s1 || !t1 || !w2 || !s2 || !t2 || !w3 || !s3 || !t3) return PRCNN_BAD_SHAPE;
+    Chain2Args a = {};
+    a.rows = rows; a.n = n; a.m = m; a.ns = nsample; a.xyz = xyz; a.new_xyz = new_xyz; a.idx = idx;
+    a.table = table; a.ldt = ldt; a.c1 = c1; a.c2 = c2; a.c3 = c3;
+    a.wx = w_xyz; a.s1 = s1; a.t1 = t1; a.w2 = w2; a.s2 = s2; a.t2 = t2; a.w3 = w3; a.s3 = s3; a.t3 = t3;
+    a.out = out; a.ldo = ldo;
+    hipStream_t st = to_stream(stream);
+    const long long tiles = (rows + 31) / 32;
+    static const int nw_env = getenv("PRCNN_CHAIN2_NW") ? atoi(getenv("PRCNN_CHAIN2_NW")) : 0;   // tuning aid
+#define PRCNN_CHAIN2_LAUNCH(C2P_, NW_)                                                                  \
+    do {                                                                                                \
+        long long blocks = (tiles + NW_ - 1) / NW_;                                                     \
+        if (blocks > 256) blocks = 256;              /* weights are loaded once per workgroup */       \
+        hipLaunchKernelGGL((sa_chain2_kernel<C2P_, NW_>), dim3((unsigned)blocks), dim3(NW_ * 64), 0, st, a); \
+    } while (0)
+    if (c2 <= 64) {
+        // 48 KB of weights + NW x 8.7 KB tiles: one workgroup per CU
+        if (nw_env == 4) PRCNN_CHAIN2_LAUNCH(64, 4);
+        else if (nw_env == 12) PRCNN_CHAIN2_LAUNCH(64, 12);
+        else if (nw_env == 8) PRCNN_CHAIN2_LAUNCH(64, 8);
+        else PRCNN_CHAIN2_LAUNCH(64, 12);   // measured (b16, 262144 rows): 4 waves 112 us, 8: 89, 12: 81
+    } else {
+        // 72 KB of weights + NW x 12.8 KB tiles
+        if (nw_env == 4) PRCNN_CHAIN2_LAUNCH(96, 4);
+        else PRCNN_CHAIN2_LAUNCH(96, 6);
+    }
+#undef PRCNN_CHAIN2_LAUNCH
+    PRCNN_LAUNCH_CHECK();
+    return PRCNN_OK;
 }

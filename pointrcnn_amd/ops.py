@@ -561,6 +561,51 @@ def sa_group_add_layer(xyz, new_xyz, idx, table, col, cout, w_xyz, scale, shift,
     return out
 
 
+def sa_chain2_supported(mlp, nsample, precision):
+    """Shapes the hoisted-scale chain kernel serves (see prcnn_sa_group_add_mlp2_pool)."""
+    return (SA_CHAIN2 and precision == PRECISION_FP32 and len(mlp) == 3 and mlp[0] <= 64 and mlp[1] <= 96
+            and mlp[2] <= 128 and nsample in (16, 32))
+
+
+SA_CHAIN2 = True     # False: hoisted scales always run layer by layer (tests compare the two)
+
+
+def sa_group_add_mlp2_pool(xyz, new_xyz, idx, table, col, w_xyz, layers, out=None, out_col=0):
+    """A hoisted scale in one launch: table-gather first layer (see sa_group_add_layer) + two
+    shared-MLP layers + max over nsample.  layers = [(W, scale, shift)] * 3; only the scale /
+    shift of layers[0] are used (its weights are `table` and w_xyz (3,c1)).  Returns (b,m,c3), or
+    writes into out[..., out_col:out_col+c3]."""
+    xyz = _dev(xyz, torch.float32, "sa_group_add_mlp2_pool xyz", 3, 3)
+    new_xyz = _dev(new_xyz, torch.float32, "sa_group_add_mlp2_pool new_xyz", 3, 3)
+    idx = _dev(idx, torch.int32, "sa_group_add_mlp2_pool idx", 3)
+    table = _dev(table, torch.float32, "sa_group_add_mlp2_pool table", 3)
+    w_xyz = _dev(w_xyz, torch.float32, "sa_group_add_mlp2_pool w_xyz", 2)
+    b, n, _ = xyz.shape
+    _, m, ns = idx.shape
+    ctab = table.shape[2]
+    (_, s1, t1), (W2, s2, t2), (W3, s3, t3) = [tuple(_dev(t, torch.float32, "layer") for t in L) for L in layers]
+    c1, c2, c3 = w_xyz.shape[1], W2.shape[1], W3.shape[1]
+    if table.shape[0] != b or table.shape[1] != n or col < 0 or col + c1 > ctab:
+        raise ValueError("sa_group_add_mlp2_pool: table %s does not hold columns [%d,%d) for %d x %d points"
+                         % (tuple(table.shape), col, col + c1, b, n))
+    if w_xyz.shape[0] != 3 or W2.shape[0] != c1 or W3.shape[0] != c2 or s1.shape[0] != c1:
+        raise ValueError("sa_group_add_mlp2_pool: layer shapes do not chain")
+    if out is None:
+        res = torch.empty((b, m, c3), dtype=torch.float32, device=xyz.device)
+        optr, ldo = res.data_ptr(), c3
+    else:
+        res, ldo, optr = out, out.shape[-1], out.data_ptr() + 4 * out_col
+    rows = b * m * ns
+    flops = 2 * rows * (3 * c1 + c1 * c2 + c2 * c3)
+    _lib.check(_run("sa_chain2", {"shape": "rows%d N%d-%d-%d pool%d" % (rows, c1, c2, c3, ns), "flops": flops,
+                                  "bytes": rows * (4 + 12 + 4 * c1) + 4 * (rows // ns) * c3},
+                    lambda: _lib.lib().prcnn_sa_group_add_mlp2_pool(
+        b, n, m, ns, _p(xyz), _p(new_xyz), _p(idx), table.data_ptr() + 4 * col, ctab, c1, c2, c3, _p(w_xyz),
+        _p(s1), _p(t1), _p(W2), _p(s2), _p(t2), _p(W3), _p(s3), _p(t3), optr, ldo, _stream())),
+        "sa_group_add_mlp2_pool")
+    return res
+
+
 def sa_chain_supported(c, mlp, nsample, precision):
     """Shapes the fully fused set-abstraction kernel serves (see prcnn_sa_group_mlp3_pool)."""
     return (precision == PRECISION_FP32 and len(mlp) == 3 and c + 3 <= 8 and mlp[0] <= 32

@@ -258,6 +258,16 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
             ops.sa_group_mlp3_pool(xyz, points, new_xyz, idx, layers, xyz_first=False, out=out, out_col=col)
             col += mlp[-1]
             continue
+        if fusable and split[i] and ops.sa_chain2_supported(mlp, nsample, precision):
+            # the whole hoisted scale in one launch: table gather + 2 MFMA layers + max-pool
+            name = '%s/conv%d_0' % (scope, i)
+            W, s, t = store.layer(name, c_feat + 3, mlp[0], bn)
+            wx = store.derived('__wx/' + name, lambda: W[c_feat:].contiguous())
+            layers = [(W, s, t)] + [store.layer('%s/conv%d_%d' % (scope, i, j), mlp[j - 1], mlp[j], bn)
+                                    for j in (1, 2)]
+            ops.sa_group_add_mlp2_pool(xyz, new_xyz, idx, table, tcol[i], wx, layers, out=out, out_col=col)
+            col += mlp[-1]
+            continue
         if fusable and split[i]:
             name = '%s/conv%d_0' % (scope, i)
             W, s, t = store.layer(name, c_feat + 3, mlp[0], bn)

@@ -191,6 +191,39 @@ def test_sa_module_msg_matches_oracle_composition(cuda, fused):
     close(npy(feats), ofeats, ops.PRECISION_FP32)
 
 
+@pytest.mark.parametrize("c_feat,npoint,mlps", [(96, 333, [[64, 64, 128], [64, 96, 128]]),     # RPN level 2 (rpn.py:170-173)
+                                                 (7, 50, [[40, 90, 100], [64, 33, 128]])])      # odd widths, ragged tiles
+def test_sa_chain2_hoisted_scale_matches_oracle_and_layerwise(cuda, c_feat, npoint, mlps):
+    """prcnn_sa_group_add_mlp2_pool (table gather + 2 MFMA layers + max-pool in one launch) through
+    pointnet_sa_module_msg: against the oracle composition and against the layer-by-layer path."""
+    rng = np.random.default_rng(23)
+    pc = S.kitti_batch(30, 2, 2048)
+    xyz = pc[:, :, :3].copy()
+    pts = rng.standard_normal((2, 2048, c_feat)).astype(np.float32)
+    radii, nsamples = [0.5, 1.0], [16, 32]
+    store = PU.ParamStore(seed=4, device=cuda, randomize_bn=True)
+    calls = []
+    real = ops.sa_group_add_mlp2_pool
+    ops.sa_group_add_mlp2_pool = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        new_xyz, feats = PU.pointnet_sa_module_msg(dev(xyz, cuda), dev(pts, cuda), npoint, radii, nsamples, mlps,
+                                                   False, None, scope='layer2', params=store)
+    finally:
+        ops.sa_group_add_mlp2_pool = real
+    assert len(calls) == 2                                         # both scales took the one-launch path
+    ops.SA_CHAIN2 = False
+    try:
+        _, feats_lw = PU.pointnet_sa_module_msg(dev(xyz, cuda), dev(pts, cuda), npoint, radii, nsamples, mlps,
+                                                False, None, scope='layer2', params=store)
+    finally:
+        ops.SA_CHAIN2 = True
+    layers = [[tuple(npy(t) for t in store['layer2/conv%d_%d' % (i, j)]) for j in range(3)] for i in range(2)]
+    oxyz, ofeats = _oracle_sa_msg(xyz, pts, npoint, radii, nsamples, mlps, layers)
+    assert np.array_equal(npy(new_xyz), oxyz)
+    close(npy(feats), ofeats, ops.PRECISION_FP32)
+    close(npy(feats), npy(feats_lw), ops.PRECISION_FP32)
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_sa_module_ssg_group_all_and_fp_match_oracle(cuda, fused):
     fr = S.frustum_batch(3, 4, 512, channels=3)

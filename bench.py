@@ -466,6 +466,7 @@ def main():
                 ("mlp_layer", "rows262144 K260 N128 pool1"): "mlp_kernel<2, 2, 2, 2, false, false, 16> grid_threads=524288",
                 ("mlp_layer", "rows524288 K96 N128 pool32"): "mlp_kernel<2, 2, 2, 2, false, false, 16> grid_threads=1048576",
                 ("sa_chain", "rows2097152 K4 N32-32-64 pool32"): "sa_chain_kernel<4, 32, 32, 64, 32, 32>",
+                ("sa_chain2", "rows524288 N64-96-128 pool32"): "sa_chain2_kernel<96, 6>",
             }
             pk = pmc_keys.get((best["kernel"], best["shape"]))
             if pk and precision == 0 and args.batch == BATCH and os.path.exists(pmc_path):

@@ -250,26 +250,32 @@ __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         __syncthreads();
         if (ch + 1 < nchunks) load_chunk((ch + 1) * BK);
         if (!BF16) {
-            constexpr int KS = BK / 2;                   // MFMA steps per chunk; phys k = kh*KS + s
-            f32x4 af[TM][KS / 4];
+            // A chunk is walked in sub-chunks of 16: MFMA step s of sub-chunk u multiplies physical
+            // k = 16u + 8*kh + s, so every output element accumulates its products in the same
+            // order whatever the chunk depth (results do not depend on the launch heuristics).
+            constexpr int SUBS = BK / 16;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const unsigned *p = &As[((wm * TM + i) * 32 + li) * AS + kh * KS];
+            for (int u = 0; u < SUBS; ++u) {
+                f32x4 af[TM][2];
 #pragma unroll
-                for (int v = 0; v < KS / 4; ++v) af[i][v] = *reinterpret_cast<const f32x4 *>(p + 4 * v);
-            }
+                for (int i = 0; i < TM; ++i) {
+                    const unsigned *p = &As[((wm * TM + i) * 32 + li) * AS + u * 16 + kh * 8];
+                    af[i][0] = *reinterpret_cast<const f32x4 *>(p);
+                    af[i][1] = *reinterpret_cast<const f32x4 *>(p + 4);
+                }
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                float bf[TN];
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    bf[j] = __builtin_bit_cast(float, Bs[(kh * KS + s) * BS + (wn * TN + j) * 32 + li]);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int s = 0; s < 8; ++s) {
+                    float bf[TN];
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s >> 2][s & 3], bf[j],
-                                                                         acc[i][j], 0, 0, 0);
+                        bf[j] = __builtin_bit_cast(float, Bs[(u * 16 + kh * 8 + s) * BS + (wn * TN + j) * 32 + li]);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s >> 2][s & 3], bf[j],
+                                                                             acc[i][j], 0, 0, 0);
+                }
             }
         } else {
             // two k-steps of 16: lane (li, kh) holds k = 16*s + 8*kh + 0..7
@@ -427,6 +433,10 @@ static int launch_mlp(const MlpArgs &a, hipStream_t st)
     // measured (profiles/r01_mlp_tile_sweep.txt): 32-deep fp32 chunks do not pay (the kernel is
     // MFMA-issue bound, not barrier bound), so fp32 stays at 16
     int kb = BF16 ? 32 : 16;
+    // except on shallow grids with a long K (few rows: FP levels on 64 / 256 points per cloud), where a
+    // workgroup has its SIMDs to itself and the two barriers per chunk are exposed: rows4096 K512
+    // N512 31.5 -> 28.9 us, rows1024 K1024 N512 47 -> 32 us with 32-deep chunks
+    if (!BF16 && a.cin >= 512 && rb * ((a.cout + bn - 1) / bn) <= 256) kb = 32;
     if (const char *f = getenv("PRCNN_MLP_KB")) kb = atoi(f);   // tuning aid (16 / 32)
     dim3 grid((unsigned)rb, (a.cout + bn - 1) / bn);
 #define PRCNN_MLP_LAUNCH(WM_, WN_, TM_, TN_, KB_) \

@@ -49,6 +49,19 @@ def test_mlp_layer(cuda, prec, rows, cin, cout):
         close(got, O.mlp_layer(x, W, s, t, relu), prec)
 
 
+def test_mlp_layer_is_batch_invariant(cuda):
+    """The launch heuristics (tile width, K-chunk depth) depend on the number of rows; the value of a
+    row must not: the first 4096 rows of a 65536-row launch equal a 4096-row launch bit for bit."""
+    g = torch.Generator(device='cpu').manual_seed(11)
+    x = torch.randn((65536, 512), generator=g).to(cuda)
+    W = (torch.randn((512, 512), generator=g) * 0.05).to(cuda)
+    s = torch.rand((512,), generator=g).add_(0.5).to(cuda); t = torch.randn((512,), generator=g).to(cuda)
+    big = ops.mlp_layer(x, W, s, t)
+    small = ops.mlp_layer(x[:4096].contiguous(), W, s, t)
+    tiny = ops.mlp_layer(x[:100].contiguous(), W, s, t)
+    assert torch.equal(big[:4096], small) and torch.equal(big[:100], tiny)
+
+
 @pytest.mark.parametrize("prec", [ops.PRECISION_FP32, ops.PRECISION_BF16])
 @pytest.mark.parametrize("groups,ns,cin,cout", [(40, 16, 16, 32), (9, 32, 64, 128), (5, 64, 64, 128),
                                                 (3, 128, 96, 128), (7, 32, 256, 512), (4, 48, 20, 24),

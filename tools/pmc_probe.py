@@ -43,6 +43,12 @@ def main():
     W96 = torch.randn(96, 128, generator=g).mul_(0.1).to(dev)
     (idx1, _), = ops.query_ball_point_msg([0.5], [32], xyz, new1)
     one = lambda c: (torch.ones(c, device=dev), torch.zeros(c, device=dev))
+    # RPN level 2, second scale as one launch (sa_chain2): table (b,4096,64), [64,96,128], nsample 32
+    tab = torch.randn(b, 4096, 64, generator=g).to(dev)
+    wx = torch.randn(3, 64, generator=g).mul_(0.3).to(dev)
+    L2 = [(None,) + one(64), (torch.randn(64, 96, generator=g).mul_(0.1).to(dev),) + one(96),
+          (torch.randn(96, 128, generator=g).mul_(0.1).to(dev),) + one(128)]
+    L2[0] = (wx,) + one(64)
     torch.cuda.synchronize()
     work = {
         "group_point_kernel<4>": b * 1024 * 32 * (4 + 8 * 96),
@@ -55,6 +61,7 @@ def main():
         "bq_culled_kernel<2> n16384 m4096 r0.1/0.5 ns16/32": b * (12 * 16384 + 12 * 4096 + 4 * 4096 * 48 + 8 * 4096),
         "sa_chain_kernel<4, 32, 32, 64> rows2097152": b * 4096 * 32 * (4 + 16) + 4 * b * 4096 * 64,
         "mlp_kernel<4, 1, 1, 2, true, false>": b * 1024 * 32 * (4 + 4 * 99) + 4 * b * 1024 * 32 * 64,
+        "sa_chain2_kernel<96, 6> rows524288 N64-96-128": b * 1024 * 32 * (4 + 12 + 4 * 64) + 4 * b * 1024 * 128,
     }
     for _ in range(REPS):
         ops.group_point(f1, idx2)
@@ -64,6 +71,7 @@ def main():
         ops.mlp_layer(x608, W608, *one(256))
         ops.mlp_layer(x96, W96, *one(128), pool=32)
         ops.sa_group_mlp3_pool(xyz, feats, new1, idx1, W4)
+        ops.sa_group_add_mlp2_pool(new1, new2, idx2, tab, 0, wx, L2)
         ops.sa_group_mlp_layer(new1, f1, new2, idx2, W99, *one(64))
         ops.query_ball_point_msg([0.1, 0.5], [16, 32], xyz, new1)
         ops.farthest_point_sample(4096, xyz)

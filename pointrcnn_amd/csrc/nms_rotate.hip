@@ -164,6 +164,7 @@ __global__ __launch_bounds__(64) void mask_kernel(int n, int words, double thr, 
     const BoxRec *rec = rec_all + (size_t)blockIdx.z * n;
     unsigned long long *mask = mask_all + (size_t)blockIdx.z * n * words;
     __shared__ BoxRec colb[64];
+    __shared__ double colu[64], colv[64], colr[64];
     __shared__ unsigned long long bits[64];
     __shared__ unsigned short pairs[64 * 64];
     // linear block id -> (rb, cb) with cb >= rb: row block rb owns (words - rb) blocks
@@ -184,22 +185,32 @@ __global__ __launch_bounds__(64) void mask_kernel(int n, int words, double thr, 
         const int lane = threadIdx.x;
         const int r = rb * 64 + lane;
         const int cidx = cb * 64 + lane;
-        if (cidx < n) colb[lane] = rec[cidx];
+        BoxRec cl = {};
+        if (cidx < n) cl = rec[cidx];
+        colb[lane] = cl;
+        colu[lane] = cl.u; colv[lane] = cl.v; colr[lane] = cl.rad;
         bits[lane] = 0ull;
         __syncthreads();
-        BoxRec me;
+        BoxRec me = {};
         if (r < n) me = rec[r];
-        // screen: circumscribed circles
+        // screen: circumscribed circles, branch-free over the 64 columns (centres and radii as
+        // separate LDS arrays: three broadcast reads per column, unrolled); columns past n, at or
+        // before the row, and rows past n are masked out afterwards
         unsigned long long cand = 0ull;
-        if (r < n) {
+#pragma unroll 16
+        for (int k = 0; k < 64; ++k) {
+            const double dx = colu[k] - me.u, dy = colv[k] - me.v;
+            const double rr = colr[k] + me.rad;
+            cand |= (unsigned long long)(dx * dx + dy * dy <= rr * rr) << k;
+        }
+        {
             const int cmax = min(64, n - cb * 64);
-            for (int k = 0; k < cmax; ++k) {
-                const int c = cb * 64 + k;
-                if (c <= r) continue;
-                const double dx = colb[k].u - me.u, dy = colb[k].v - me.v;
-                const double rr = colb[k].rad + me.rad;
-                if (dx * dx + dy * dy <= rr * rr) cand |= 1ull << k;
-            }
+            unsigned long long keep = cmax >= 64 ? ~0ull : ((1ull << cmax) - 1ull);
+            const int first = r - cb * 64 + 1;                 // first column index past the row
+            if (first >= 64) keep = 0ull;
+            else if (first > 0) keep &= ~0ull << first;
+            if (r >= n) keep = 0ull;
+            cand &= keep;
         }
         // compact the candidate pairs of the whole wave into LDS
         const int mine = __builtin_popcountll(cand);
@@ -250,14 +261,20 @@ __global__ __launch_bounds__(64) void mask_all_kernel(int n, int words,
 
 // Serial sweep by one wave.  `removed` lives in LDS (words <= SWEEP_MAX_WORDS).
 constexpr int SWEEP_MAX_WORDS = 8192;   // n <= 524288
+constexpr int SWEEP_SPEC = 4;           // mask rows fetched together (words <= 2048, i.e. n <= 131072; else 1); 8 measured no faster
+constexpr int SWEEP_SPEC_WORDS = 8192;  // LDS words for them
 
-__global__ __launch_bounds__(64) void sweep_kernel(int n, int words, int max_out,
+static int sweep_nspec(int words) { return words <= SWEEP_SPEC_WORDS / SWEEP_SPEC ? SWEEP_SPEC : 1; }
+static size_t sweep_lds_bytes(int words) { return (size_t)words * (1 + sweep_nspec(words)) * sizeof(unsigned long long); }
+
+__global__ __launch_bounds__(64) void sweep_kernel(int n, int words, int max_out, int nspec,
                                                    const unsigned long long *__restrict__ mask_all,
                                                    const int *__restrict__ order_all,
                                                    long long *__restrict__ keep_all,
                                                    int *__restrict__ n_keep_all)
 {
-    __shared__ unsigned long long removed[SWEEP_MAX_WORDS];
+    extern __shared__ unsigned long long sweep_lds[];     // removed[words], spec[nspec][words]
+    unsigned long long *removed = sweep_lds, *spec = sweep_lds + words;
     const unsigned long long *mask = mask_all + (size_t)blockIdx.x * n * words;
     const int *order = order_all + (size_t)blockIdx.x * n;
     long long *keep = keep_all + (size_t)blockIdx.x * max_out;
@@ -270,32 +287,98 @@ __global__ __launch_bounds__(64) void sweep_kernel(int n, int words, int max_out
         removed[w] = v;
     }
     __syncthreads();
-    int nk = 0;
-    int cur = 0;                                 // first rank not yet examined
-    while (nk < max_out && cur < n) {
-        // find the first zero bit at position >= cur, 64 words per step
-        int found = -1;
-        for (int w0 = cur >> 6; w0 < words && found < 0; w0 += 64) {
+    // Every kept box costs one dependent read of its mask row (global memory, ~1 us): the sweep is
+    // latency-bound on it.  So the rows of the next SPEC unsuppressed ranks are fetched together,
+    // speculatively (a later one may be suppressed by an earlier one of the same batch: it is then
+    // skipped, exactly as the serial order would), and applied in rank order from LDS.
+    auto first_open = [&](int from) -> int {     // first zero bit of `removed` at position >= from
+        for (int w0 = from >> 6; w0 < words; w0 += 64) {
             const int w = w0 + lane;
             unsigned long long z = w < words ? ~removed[w] : 0ull;
-            if (w == (cur >> 6)) z &= ~0ull << (cur & 63);
+            if (w == (from >> 6)) z &= ~0ull << (from & 63);
             const unsigned long long has = __ballot(z != 0ull);
             if (has) {
                 const int fl = __builtin_ctzll(has);
-                const int bit = __builtin_ctzll(__shfl(z, fl) | 0ull);
-                found = (w0 + fl) * 64 + bit;
+                return (w0 + fl) * 64 + __builtin_ctzll(__shfl(z, fl));
             }
         }
-        if (found < 0 || found >= n) break;
-        if (lane == 0) keep[nk] = order[found];
-        ++nk;
-        // removed |= mask row of `found` (only words >= found/64 matter)
-        const unsigned long long *row = mask + (size_t)found * words;
-        for (int w = (found >> 6) + lane; w < words; w += 64) removed[w] |= row[w];
+        return -1;
+    };
+    int nk = 0;
+    long long mykeep = 0;
+    int cur = 0;                                 // first rank not yet examined
+    while (nk < max_out && cur < n) {
+        // (fully unrolled with compile-time indices: cands stays in registers)
+        int cands[SWEEP_SPEC];
+        int nc = 0, last = cur - 1;
+        bool more = true;
+#pragma unroll
+        for (int q = 0; q < SWEEP_SPEC; ++q) {
+            cands[q] = -1;
+            if (more && q < nspec) {
+                const int f = first_open(last + 1);
+                if (f < 0 || f >= n) more = false;
+                else { cands[q] = f; last = f; nc = q + 1; }
+            }
+        }
+        if (nc == 0) break;
+        // all loads of a slab (4 words per lane and row) are issued before the first is used
+        int ord[SWEEP_SPEC];                     // original indices of the candidates (uniform loads)
+#pragma unroll
+        for (int q = 0; q < SWEEP_SPEC; ++q) ord[q] = q < nc ? order[cands[q]] : 0;
+        for (int base = (cands[0] >> 6) & ~63; base < words; base += 256) {
+            unsigned long long v[SWEEP_SPEC][4];
+#pragma unroll
+            for (int q = 0; q < SWEEP_SPEC; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int w = base + j * 64 + lane;
+                    v[q][j] = (q < nc && w < words) ? mask[(size_t)cands[q] * words + w] : 0ull;
+                }
+#pragma unroll
+            for (int q = 0; q < SWEEP_SPEC; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int w = base + j * 64 + lane;
+                    if (q < nc && w < words) spec[q * words + w] = v[q][j];
+                }
+        }
         __syncthreads();
-        cur = found + 1;
+#pragma unroll
+        for (int q = 0; q < SWEEP_SPEC; ++q) {
+            if (q < nc && nk < max_out) {
+                const int f = cands[q];
+                const bool gone = q > 0 && ((removed[f >> 6] >> (f & 63)) & 1ull);   // suppressed inside the batch
+                if (!gone) {
+                    // kept indices collect in registers (lane nk % 64) and leave 64 at a time: a
+                    // store per kept box would be waited for at the barrier below
+                    if (lane == (nk & 63)) mykeep = ord[q];
+                    ++nk;
+                    if ((nk & 63) == 0) keep[nk - 64 + lane] = mykeep;
+                    // removed |= mask row of f (only words >= f/64 matter)
+                    for (int w = (f >> 6) + lane; w < words; w += 64) removed[w] |= spec[q * words + w];
+                    __syncthreads();
+                }
+            }
+        }
+        cur = last + 1;
     }
+    if (lane < (nk & 63)) keep[(nk & ~63) + lane] = mykeep;
     if (lane == 0) *n_keep = nk;
+}
+
+static int launch_sweep(int batch, int n, int words, int max_out, const unsigned long long *mask, const int *order,
+                        long long *keep, int *n_keep, hipStream_t st)
+{
+    const size_t lds = sweep_lds_bytes(words);
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void *)sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return PRCNN_HIP_ERROR;
+    }
+    hipLaunchKernelGGL(sweep_kernel, dim3(batch), dim3(64), lds, st, n, words, max_out, sweep_nspec(words), mask,
+                       order, keep, n_keep);
+    return PRCNN_OK;
 }
 
 struct NmsLayout {
@@ -424,8 +507,8 @@ extern "C" int prcnn_nms_aabb_batched(int batch, int n, const float *boxes, cons
     const long long nblk = (long long)L.words * (L.words + 1) / 2;
     hipLaunchKernelGGL(aabb_mask_kernel, dim3((unsigned)nblk, 1, batch), dim3(64), 0, st, n, L.words,
                        iou_threshold, rec, mask);
-    hipLaunchKernelGGL(sweep_kernel, dim3(batch), dim3(64), 0, st, n, L.words, max_output_size, mask, order,
-                       (long long *)keep, n_keep);
+    if (launch_sweep(batch, n, L.words, max_output_size, mask, order, (long long *)keep, n_keep, st) != PRCNN_OK)
+        return PRCNN_HIP_ERROR;
     PRCNN_LAUNCH_CHECK();
     return PRCNN_OK;
 }
@@ -624,8 +707,8 @@ extern "C" int prcnn_nms_rotate_batched(int batch, int n, const double *boxes, c
         hipLaunchKernelGGL(mask_all_kernel, dim3(2048, 1, batch), dim3(64), 0, st, n, L.words, mask);
     }
     PRCNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sweep_kernel, dim3(batch), dim3(64), 0, st, n, L.words, max_output_size, mask,
-                       order, (long long *)keep, n_keep);
+    if (launch_sweep(batch, n, L.words, max_output_size, mask, order, (long long *)keep, n_keep, st) != PRCNN_OK)
+        return PRCNN_HIP_ERROR;
     PRCNN_LAUNCH_CHECK();
     return PRCNN_OK;
 }

@@ -221,6 +221,54 @@ int prcnn_sa_group_mlp3_pool(int b, int n, int m, int nsample, int c, const floa
                              const float *t2, const float *w3, const float *s3, const float *t3,
                              float *out, int64_t ldo, prcnn_stream_t stream);
 
+/* ---- duplicate-free groups (additive; identical results) -----------------------------------
+ * query_ball_point pads a ball of cnt < nsample points with copies of its first hit
+ * (tf_grouping_g.cu:26-29): the grouped tensor repeats that row and the max over the group does
+ * not need the copies.  prcnn_ball_count_classes sorts the `groups` = b*m centroids of one scale
+ * by pts_cnt into six classes (cnt <= 1, 2, 4, 8, 16, 32): cls_list (6, groups) int32 holds the
+ * centroid numbers of each class (order inside a class unspecified), cls_count (8 int32, the
+ * first six used) their sizes.  The *_classes forms of the chain kernels below then evaluate only
+ * the first 1 / 2 / 4 / 8 / 16 / 32 slots of each centroid of a class: bit-identical output, work
+ * proportional to the distinct rows.  nsample must be 16 or 32 as for the plain forms. */
+int prcnn_ball_count_classes(int64_t groups, const int *pts_cnt, int *cls_list, int *cls_count,
+                             prcnn_stream_t stream);
+int prcnn_sa_group_mlp3_pool_classes(int b, int n, int m, int nsample, int c, const float *xyz,
+                                     const float *feats, const float *new_xyz, const int *idx,
+                                     int xyz_first, int c1, int c2, int c3, const float *w1,
+                                     const float *s1, const float *t1, const float *w2,
+                                     const float *s2, const float *t2, const float *w3,
+                                     const float *s3, const float *t3, float *out, int64_t ldo,
+                                     const int *cls_list, const int *cls_count,
+                                     prcnn_stream_t stream);
+int prcnn_sa_group_add_mlp2_pool_classes(int b, int n, int m, int nsample, const float *xyz,
+                                         const float *new_xyz, const int *idx, const float *table,
+                                         int64_t ldt, int c1, int c2, int c3, const float *w_xyz,
+                                         const float *s1, const float *t1, const float *w2,
+                                         const float *s2, const float *t2, const float *w3,
+                                         const float *s3, const float *t3, float *out, int64_t ldo,
+                                         const int *cls_list, const int *cls_count,
+                                         prcnn_stream_t stream);
+
+/* The same idea for scales too wide for the chain kernels, as a compacted row list: centroid g
+ * contributes its max(cnt,1) distinct slots as rows off[g] .. off[g+1]-1 (rowpi: point row b*n
+ * space, rowci: centroid number; all int32, capacity b*m*nsample rows; off has b*m+1 entries;
+ * *rows_dev = number of rows).  prcnn_sa_rows_add_layer is prcnn_sa_group_add_layer over such rows,
+ * prcnn_mlp_layer_n is prcnn_mlp_layer with the row count read from device memory (max_rows sizes
+ * the grid; tiles past *rows_dev leave at once), and prcnn_segment_max takes the maximum over
+ * each centroid's rows: together they give the pooled features of the layer-by-layer path, bit
+ * for bit, with work proportional to the distinct rows. */
+int prcnn_ball_compact_rows(int b, int n, int m, int nsample, const int *idx, const int *pts_cnt,
+                            int *rowpi, int *rowci, int *off, int *rows_dev, prcnn_stream_t stream);
+int prcnn_sa_rows_add_layer(int64_t max_rows, const int *rows_dev, const int *rowpi, const int *rowci,
+                            const float *xyz, const float *new_xyz, const float *table, int64_t ldt,
+                            int cout, const float *w_xyz, const float *scale, const float *shift,
+                            int relu, int precision, float *out, int64_t ldo, prcnn_stream_t stream);
+int prcnn_mlp_layer_n(int64_t max_rows, const int *rows_dev, int cin, int cout, const float *x,
+                      int64_t ldx, const float *w, const float *scale, const float *shift, int relu,
+                      int precision, float *out, int64_t ldo, prcnn_stream_t stream);
+int prcnn_segment_max(int64_t groups, int c, const float *x, int64_t ldx, const int *off, float *out,
+                      int64_t ldo, prcnn_stream_t stream);
+
 /* Max over consecutive groups of `nsample` rows, models/pointnet_util.py:126,192
  * (tf.reduce_max over the nsample axis) for group sizes the fused epilogue of
  * prcnn_mlp_layer does not cover (pool must there be 16, 32, 64 or 128).

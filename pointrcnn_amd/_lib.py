@@ -46,6 +46,15 @@ SIGNATURES = {
                                       _i, _i, _i, _vp, _i64, _vp]),
     "prcnn_sa_group_mlp3_pool": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i] + [_vp] * 9 +
                                  [_vp, _i64, _vp]),
+    "prcnn_ball_count_classes": (_i, [_i64, _vp, _vp, _vp, _vp]),
+    "prcnn_sa_group_mlp3_pool_classes": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i] + [_vp] * 9 +
+                                         [_vp, _i64, _vp, _vp, _vp]),
+    "prcnn_sa_group_add_mlp2_pool_classes": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i] + [_vp] * 9 +
+                                             [_vp, _i64, _vp, _vp, _vp]),
+    "prcnn_ball_compact_rows": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "prcnn_sa_rows_add_layer": (_i, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _i, _i, _vp, _i64, _vp]),
+    "prcnn_mlp_layer_n": (_i, [_i64, _vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _i, _i, _vp, _i64, _vp]),
+    "prcnn_segment_max": (_i, [_i64, _i, _vp, _i64, _vp, _vp, _i64, _vp]),
     "prcnn_max_pool": (_i, [_i64, _i, _i, _vp, _i64, _vp, _i64, _vp]),
     "prcnn_three_nn_sorted_workspace_bytes": (_sz, [_i, _i, _i]),
     "prcnn_three_nn_sorted": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

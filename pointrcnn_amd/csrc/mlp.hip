@@ -45,9 +45,15 @@ struct MlpArgs {
     // grouped row): acc[row][col] += add[(bi*n + idx[row]) * ldadd + col]
     const float *add;
     long long ldadd;
+    // compacted rows (duplicate-free groups, see prcnn_ball_compact_rows): the number of rows is read
+    // from device memory (rows is then the capacity the grid was sized for), and the gather prologue
+    // takes a row's point row / centroid from explicit arrays instead of the (b,m,nsample) layout
+    const int *rows_dev;
+    const int *rowpi, *rowci;
 };
 
 constexpr int MLP_THREADS = 256;
+constexpr int DYN_ROW_BLOCKS = 96;     // grid rows of the data-dependent launches (an empty workgroup costs ~0.1 us)
 constexpr int BM = 128;
 
 // ---- A-operand element sources ---------------------------------------------------------
@@ -58,13 +64,16 @@ struct RowSrc {
 };
 
 template <bool GATHER>
-__device__ __forceinline__ RowSrc make_row(const MlpArgs &a, long long r)
+__device__ __forceinline__ RowSrc make_row(const MlpArgs &a, long long r, long long rows)
 {
     RowSrc s;
-    s.valid = r < a.rows;
+    s.valid = r < rows;
     s.pi = 0; s.ci = 0;
     if (s.valid) {
-        if (GATHER) {
+        if (GATHER && a.rowpi) {
+            s.pi = a.rowpi[r];
+            s.ci = a.rowci[r];
+        } else if (GATHER) {
             const long long bi = r / ((long long)a.m * a.ns);
             s.pi = bi * a.n + a.idx[r];
             s.ci = r / a.ns;
@@ -118,7 +127,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
 // ---- kernel ---------------------------------------------------------------------------
 // WM x WN waves (WM*WN == 4), each wave owns TM x TN MFMA tiles of 32x32.
 template <int WM, int WN, int TM, int TN, bool GATHER, bool BF16, int KB, bool ADD = false>
-__global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void mlp_kernel(const MlpArgs a)
+__device__ __forceinline__ void mlp_tile(const MlpArgs &a, const long long row_block, const long long rows)
 {
     constexpr int BN = WN * TN * 32;
     constexpr int BK = BF16 ? 32 : KB;             // fp32: 16 (narrow inputs) or 32
@@ -141,14 +150,14 @@ __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, kh = lane >> 5;
-    const long long row0 = (long long)blockIdx.x * BM;
+    const long long row0 = row_block * BM;
     const int col0 = blockIdx.y * BN;
 
     // ---- staging assignment -------------------------------------------------------------
     // A: BM x BK elements; thread -> (row = tid/2, half = tid&1): BK/2 consecutive k
     constexpr int A_PER = BK / 2;                    // elements per thread
     const int arow = tid >> 1, ahalf = tid & 1;
-    const RowSrc rs = make_row<GATHER>(a, row0 + arow);
+    const RowSrc rs = make_row<GATHER>(a, row0 + arow, rows);
     if (ADD && ahalf == 0) rowpt[arow] = rs.valid ? rs.pi : -1;   // read after the K loop's barriers
     const bool a_vec = GATHER ? ((a.c & 3) == 0 && (((uintptr_t)a.feats) & 15) == 0)
                               : ((a.ldx & 3) == 0 && (((uintptr_t)a.x) & 15) == 0);
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     // Block-uniform fast-path conditions: an interior tile whose chunk lies wholly inside the
     // vector-loadable part of A / B is fetched with unconditional 16-byte loads (no per-element
     // predicates, no branches); everything else takes the general path.
-    const bool rows_full = row0 + BM <= a.rows;
+    const bool rows_full = row0 + BM <= rows;
     const int a_klimit = GATHER ? (a.xyz_first ? 0 : a.c) : a.cin;     // A columns [0, a_klimit) are contiguous in memory
     const bool a_fast = rows_full && a_vec;
     const bool b_fast = b_vec && col0 + BN <= a.cout;
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const long long row = row0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    if (cok[j] && row < a.rows) a.out[row * a.ldo + col] = acc[i][j][r];
+                    if (cok[j] && row < rows) a.out[row * a.ldo + col] = acc[i][j][r];
                 }
             }
         return;
@@ -374,11 +383,34 @@ __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         const int g = e / BN, cl = e - g * BN;
         const int col = col0 + cl;
         const long long orow = row0 / a.pool + g;
-        if (col < a.cout && orow * a.pool < a.rows) {
+        if (col < a.cout && orow * a.pool < rows) {
             float mx = Ps[(g * gpp) * BN + cl];
             for (int q = 1; q < gpp; ++q) mx = fmaxf(mx, Ps[(g * gpp + q) * BN + cl]);
             a.out[orow * a.ldo + col] = mx;
         }
+    }
+}
+
+// The kernel proper: one row block per workgroup; with a data-dependent row count (compacted
+// rows) the grid is small and every workgroup strides over the row blocks that exist (launching
+// the capacity's worth of workgroups only to have them leave costs ~0.1 us each: 100 us at 32768
+// rows of capacity, measured).
+template <int WM, int WN, int TM, int TN, bool GATHER, bool BF16, int KB, bool ADD = false>
+__global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void mlp_kernel(const MlpArgs a)
+{
+    mlp_tile<WM, WN, TM, TN, GATHER, BF16, KB, ADD>(a, blockIdx.x, a.rows);
+}
+
+// Data-dependent row count (compacted rows): a small grid whose workgroups stride over the row
+// blocks that exist.  A kernel of its own: the loop state costs the plain kernel registers (spills).
+template <int WM, int WN, int TM, int TN, bool GATHER, bool BF16, int KB, bool ADD = false>
+__global__ __launch_bounds__(MLP_THREADS) void mlp_kernel_dyn(const MlpArgs a)
+{
+    const long long r = *a.rows_dev;
+    const long long rows = r < a.rows ? r : a.rows;
+    for (long long rb = blockIdx.x; rb * (WM * TM * 32) < rows; rb += gridDim.x) {
+        mlp_tile<WM, WN, TM, TN, GATHER, BF16, KB, ADD>(a, rb, rows);
+        __syncthreads();                              // the next tile reuses the staging LDS
     }
 }
 
@@ -414,8 +446,13 @@ static int launch_mlp(const MlpArgs &a, hipStream_t st)
         // gather + 3-column product: memory-bound, the narrow tiles (no spills with the gather
         // epilogue) are the right ones whatever cout is
         const int bn = a.cout <= 32 ? 32 : 64;
-        dim3 grid((unsigned)rb, (a.cout + bn - 1) / bn);
-        if (bn == 32)
+        dim3 grid((unsigned)(a.rows_dev && rb > DYN_ROW_BLOCKS ? DYN_ROW_BLOCKS : rb), (a.cout + bn - 1) / bn);
+        if (a.rows_dev) {
+            if (bn == 32)
+                hipLaunchKernelGGL((mlp_kernel_dyn<4, 1, 1, 1, GATHER, BF16, BF16 ? 32 : 16, GATHER>), grid, dim3(MLP_THREADS), 0, st, a);
+            else
+                hipLaunchKernelGGL((mlp_kernel_dyn<4, 1, 1, 2, GATHER, BF16, BF16 ? 32 : 16, GATHER>), grid, dim3(MLP_THREADS), 0, st, a);
+        } else if (bn == 32)
             hipLaunchKernelGGL((mlp_kernel<4, 1, 1, 1, GATHER, BF16, BF16 ? 32 : 16, GATHER>), grid, dim3(MLP_THREADS), 0, st, a);
         else
             hipLaunchKernelGGL((mlp_kernel<4, 1, 1, 2, GATHER, BF16, BF16 ? 32 : 16, GATHER>), grid, dim3(MLP_THREADS), 0, st, a);
@@ -438,6 +475,18 @@ static int launch_mlp(const MlpArgs &a, hipStream_t st)
     // N512 31.5 -> 28.9 us, rows1024 K1024 N512 47 -> 32 us with 32-deep chunks
     if (!BF16 && a.cin >= 512 && rb * ((a.cout + bn - 1) / bn) <= 256) kb = 32;
     if (const char *f = getenv("PRCNN_MLP_KB")) kb = atoi(f);   // tuning aid (16 / 32)
+    if (a.rows_dev) {
+        // compacted rows: 64-column tiles, 32-deep chunks (few row blocks exist: more workgroups
+        // across the columns, shorter K loops), grid of at most DYN_ROW_BLOCKS row blocks
+        const int bnd = a.cout <= 32 ? 32 : 64;
+        dim3 gd((unsigned)(rb > DYN_ROW_BLOCKS ? DYN_ROW_BLOCKS : rb), (a.cout + bnd - 1) / bnd);
+        if (bnd == 32)
+            hipLaunchKernelGGL((mlp_kernel_dyn<4, 1, 1, 1, GATHER, BF16, 32>), gd, dim3(MLP_THREADS), 0, st, a);
+        else
+            hipLaunchKernelGGL((mlp_kernel_dyn<4, 1, 1, 2, GATHER, BF16, 32>), gd, dim3(MLP_THREADS), 0, st, a);
+        PRCNN_LAUNCH_CHECK();
+        return PRCNN_OK;
+    }
     dim3 grid((unsigned)rb, (a.cout + bn - 1) / bn);
 #define PRCNN_MLP_LAUNCH(WM_, WN_, TM_, TN_, KB_) \
     hipLaunchKernelGGL((mlp_kernel<WM_, WN_, TM_, TN_, GATHER, BF16, KB_>), grid, dim3(MLP_THREADS), 0, st, a)
@@ -542,4 +591,131 @@ extern "C" int prcnn_max_pool(int64_t groups, int nsample, int c, const float *x
                        (long long)ldo);
     PRCNN_LAUNCH_CHECK();
     return PRCNN_OK;
+}
+
+
+// ---- compacted (duplicate-free) grouped rows ------------------------------------------------
+namespace prcnn {
+
+// rows of centroid g = its max(cnt,1) distinct slots; off[g] = first row.  One workgroup walks the
+// centroids in chunks of 1024 with a running offset (b*m is a few thousand where this is used).
+__global__ __launch_bounds__(1024) void compact_rows_kernel(long long groups, int n, int m, int ns,
+                                                            const int *__restrict__ idx, const int *__restrict__ pts_cnt,
+                                                            int *__restrict__ rowpi, int *__restrict__ rowci,
+                                                            int *__restrict__ off, int *__restrict__ rows_dev)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (long long g0 = 0; g0 < groups; g0 += 1024) {
+        const long long g = g0 + tid;
+        int c = 0;
+        if (g < groups) { c = pts_cnt[g]; c = c < 1 ? 1 : (c > ns ? ns : c); }
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int base = carry;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        const int first = base + incl - c;
+        if (g < groups) {
+            off[g] = first;
+            const long long bi = g / m;
+            for (int k = 0; k < c; ++k) {
+                rowpi[first + k] = (int)(bi * n + idx[g * ns + k]);
+                rowci[first + k] = (int)g;
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) carry = base + incl;
+        __syncthreads();
+    }
+    if (tid == 0) { off[groups] = carry; *rows_dev = carry; }
+}
+
+// out[g][:] = max over rows off[g] .. off[g+1]-1 of x (one wave per group, lanes over columns)
+__global__ __launch_bounds__(256) void segment_max_kernel(long long groups, int c, const float *__restrict__ x,
+                                                          long long ldx, const int *__restrict__ off,
+                                                          float *__restrict__ out, long long ldo)
+{
+    const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= groups) return;
+    const int lane = threadIdx.x & 63;
+    const int r0 = off[g], r1 = off[g + 1];
+    for (int col = lane; col < c; col += 64) {
+        float mx = x[(long long)r0 * ldx + col];
+        for (int r = r0 + 1; r < r1; ++r) mx = fmaxf(mx, x[(long long)r * ldx + col]);
+        out[g * ldo + col] = mx;
+    }
+}
+
+}  // namespace prcnn
+
+extern "C" int prcnn_ball_compact_rows(int b, int n, int m, int nsample, const int *idx, const int *pts_cnt,
+                                       int *rowpi, int *rowci, int *off, int *rows_dev, prcnn_stream_t stream)
+{
+    if (b < 0 || n <= 0 || m < 0 || nsample <= 0) return PRCNN_BAD_SHAPE;
+    if (!rows_dev || !off) return PRCNN_BAD_SHAPE;
+    const long long groups = (long long)b * m;
+    if (groups * nsample > 0x7fffffffLL || (long long)b * n > 0x7fffffffLL) return PRCNN_UNSUPPORTED;
+    if (groups > 0 && (!idx || !pts_cnt || !rowpi || !rowci)) return PRCNN_BAD_SHAPE;
+    hipLaunchKernelGGL(prcnn::compact_rows_kernel, dim3(1), dim3(1024), 0, to_stream(stream), groups, n, m, nsample, idx,
+                       pts_cnt, rowpi, rowci, off, rows_dev);
+    PRCNN_LAUNCH_CHECK();
+    return PRCNN_OK;
+}
+
+extern "C" int prcnn_segment_max(int64_t groups, int c, const float *x, int64_t ldx, const int *off, float *out,
+                                 int64_t ldo, prcnn_stream_t stream)
+{
+    if (groups < 0 || c <= 0 || ldx < c || ldo < c) return PRCNN_BAD_SHAPE;
+    if (groups == 0) return PRCNN_OK;
+    if (!x || !off || !out) return PRCNN_BAD_SHAPE;
+    hipLaunchKernelGGL(prcnn::segment_max_kernel, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, to_stream(stream),
+                       (long long)groups, c, x, (long long)ldx, off, out, (long long)ldo);
+    PRCNN_LAUNCH_CHECK();
+    return PRCNN_OK;
+}
+
+extern "C" int prcnn_mlp_layer_n(int64_t max_rows, const int *rows_dev, int cin, int cout, const float *x,
+                                 int64_t ldx, const float *w, const float *scale, const float *shift, int relu,
+                                 int precision, float *out, int64_t ldo, prcnn_stream_t stream)
+{
+    using namespace prcnn;
+    int rc = check_common(max_rows, cin, cout, w, scale, shift, 1, precision, out, ldo);
+    if (rc != PRCNN_OK) return rc;
+    if (max_rows == 0) return PRCNN_OK;
+    if (!x || ldx < cin || !rows_dev) return PRCNN_BAD_SHAPE;
+    MlpArgs a = {};
+    a.rows = max_rows; a.cin = cin; a.cout = cout; a.x = x; a.ldx = ldx; a.w = w; a.scale = scale;
+    a.shift = shift; a.relu = relu; a.pool = 1; a.out = out; a.ldo = ldo; a.rows_dev = rows_dev;
+    return precision ? launch_mlp<false, true>(a, to_stream(stream))
+                     : launch_mlp<false, false>(a, to_stream(stream));
+}
+
+extern "C" int prcnn_sa_rows_add_layer(int64_t max_rows, const int *rows_dev, const int *rowpi, const int *rowci,
+                                       const float *xyz, const float *new_xyz, const float *table, int64_t ldt,
+                                       int cout, const float *w_xyz, const float *scale, const float *shift,
+                                       int relu, int precision, float *out, int64_t ldo, prcnn_stream_t stream)
+{
+    using namespace prcnn;
+    int rc = check_common(max_rows, 3, cout, w_xyz, scale, shift, 1, precision, out, ldo);
+    if (rc != PRCNN_OK) return rc;
+    if (max_rows == 0) return PRCNN_OK;
+    if (!xyz || !new_xyz || !table || ldt < cout || !rows_dev || !rowpi || !rowci) return PRCNN_BAD_SHAPE;
+    MlpArgs a = {};
+    a.rows = max_rows; a.cin = 3; a.cout = cout; a.w = w_xyz; a.scale = scale; a.shift = shift;
+    a.relu = relu; a.pool = 1; a.out = out; a.ldo = ldo;
+    a.n = 1; a.m = 1; a.ns = 1; a.c = 0; a.xyz_first = 1;
+    a.xyz = xyz; a.feats = nullptr; a.new_xyz = new_xyz; a.idx = nullptr;
+    a.add = table; a.ldadd = ldt;
+    a.rows_dev = rows_dev; a.rowpi = rowpi; a.rowci = rowci;
+    return precision ? launch_mlp<true, true>(a, to_stream(stream))
+                     : launch_mlp<true, false>(a, to_stream(stream));
 }

@@ -25,6 +25,153 @@ typedef float f32x16c __attribute__((ext_vector_type(16)));
 typedef float f32x4c __attribute__((ext_vector_type(4)));
 typedef float f32x2c __attribute__((ext_vector_type(2)));
 
+// ---- duplicate-free groups ------------------------------------------------------------------
+// query_ball_point pads a ball that holds cnt < nsample points with copies of its first hit
+// (tf_grouping_g.cu:26-29), so the grouped tensor repeats that row nsample - cnt times and the
+// max over the group does not change if the copies are dropped.  With sparse balls most of the
+// grouped rows are such copies (KITTI-shaped scenes of 16384 points: 4.05 of 32 slots at radius
+// 0.5, 1.56 of 16 at 0.1).  prcnn_ball_count_classes sorts the centroids of a scale into six
+// classes by cnt (<= 1, 2, 4, 8, 16, 32); the chain kernels then walk, class by class, only the
+// first G = 1 / 2 / 4 / 8 / 16 / 32 slots of each centroid of that class -- all its distinct rows
+// plus padding up to the class size -- as tiles of 32 rows = 32 / G groups.  Same values, bit for
+// bit (the dropped rows are copies of a kept one).  Without class lists the kernels see one
+// class, G = nsample, holding every centroid in order: the plain layout.
+constexpr int CLS_N = 6;
+
+struct ClsArgs {
+    const int *list;       // [CLS_N][stride] centroid numbers (b*m space) per class, or null
+    const int *count;      // [CLS_N]
+    long long stride;
+};
+
+struct ClsTiles {
+    long long start[CLS_N + 1];   // first virtual tile of each class
+    int count[CLS_N];
+};
+
+__device__ __forceinline__ void cls_setup(const ClsArgs &c, long long groups, int ns, ClsTiles &t)
+{
+    long long acc = 0;
+#pragma unroll
+    for (int k = 0; k < CLS_N; ++k) {
+        int cnt;
+        if (c.list) cnt = c.count[k];
+        else cnt = (1 << k) == ns ? (int)groups : 0;
+        t.count[k] = cnt;
+        t.start[k] = acc;
+        acc += ((long long)cnt + (32 >> k) - 1) >> (5 - k);      // 32 >> k groups per tile
+    }
+    t.start[CLS_N] = acc;
+}
+
+struct ClsTile {
+    int lg;                // log2 of the class's group size
+    long long gbase;       // first group (position in the class list) of the tile
+    int count;             // groups in the class
+    const int *lst;        // the class list, or null (identity)
+};
+
+__device__ __forceinline__ ClsTile cls_tile(const ClsArgs &c, const ClsTiles &t, long long vt)
+{
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < CLS_N; ++q) k += vt >= t.start[q] ? 1 : 0;
+    ClsTile r;
+    r.lg = k;
+    r.gbase = (vt - t.start[k]) << (5 - k);
+    r.count = t.count[k];
+    r.lst = c.list ? c.list + (long long)k * c.stride : nullptr;
+    return r;
+}
+
+// centroid number (b*m space) of group position g, -1 past the end
+__device__ __forceinline__ long long cls_centroid(const ClsTile &ti, long long g)
+{
+    if (g >= ti.count) return -1;
+    return ti.lst ? (long long)ti.lst[g] : g;
+}
+
+// Output rows of a tile for this lane half: oc[e] = centroid number that entry e of
+// cls_pool_store writes (-1: none).  Looked up once per tile, before any store (the stores to
+// `out` would otherwise order every later load of the class list behind them).
+__device__ __forceinline__ void cls_out_rows(const ClsTile &ti, int kh, int (&oc)[16])
+{
+    const int lg = ti.lg;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        long long g = -1;                      // group position of entry e, -1 = entry unused
+        if (lg == 0) g = (e & 3) + 8 * (e >> 2) + 4 * kh;
+        else if (lg == 1) { if (e < 8) g = ((((2 * e) & 3) + 8 * ((2 * e) >> 2) + 4 * kh) >> 1); }
+        else if (lg == 2) { if (e < 4) g = 2 * e + kh; }
+        else if (lg == 3) { if (e < 4 && kh == 0) g = e; }
+        else if (lg == 4) { if (e < 2 && kh == 0) g = e; }
+        else { if (e < 1 && kh == 0) g = 0; }
+        oc[e] = g < 0 ? -1 : (int)cls_centroid(ti, ti.gbase + g);
+    }
+}
+
+// max over the groups of a 32-row tile held in the MFMA C/D layout (v[r]: row (r&3) + 8*(r>>2) +
+// 4*kh, this lane's column) and store of one value per group: out[centroid*ldo + col].
+__device__ __forceinline__ void cls_pool_store(const float (&v)[16], int lg, const int (&oc)[16], bool col_ok,
+                                               float *out, long long ldo, int col)
+{
+    if (lg == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (oc[r] >= 0 && col_ok) out[(long long)oc[r] * ldo + col] = v[r];
+    } else if (lg == 1) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            if (oc[p] >= 0 && col_ok) out[(long long)oc[p] * ldo + col] = fmaxf(v[2 * p], v[2 * p + 1]);
+    } else {
+        float b4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b4[q] = fmaxf(fmaxf(v[4 * q], v[4 * q + 1]), fmaxf(v[4 * q + 2], v[4 * q + 3]));
+        if (lg == 2) {                                   // rows 8q + 4kh .. +3 -> group 2q + kh
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (oc[q] >= 0 && col_ok) out[(long long)oc[q] * ldo + col] = b4[q];
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b4[q] = fmaxf(b4[q], __shfl_xor(b4[q], 32));     // rows 8q .. 8q+7
+        if (lg == 3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (oc[q] >= 0 && col_ok) out[(long long)oc[q] * ldo + col] = b4[q];
+        } else if (lg == 4) {
+            if (oc[0] >= 0 && col_ok) out[(long long)oc[0] * ldo + col] = fmaxf(b4[0], b4[1]);
+            if (oc[1] >= 0 && col_ok) out[(long long)oc[1] * ldo + col] = fmaxf(b4[2], b4[3]);
+        } else {
+            if (oc[0] >= 0 && col_ok) out[(long long)oc[0] * ldo + col] = fmaxf(fmaxf(b4[0], b4[1]), fmaxf(b4[2], b4[3]));
+        }
+    }
+}
+
+// One global atomic per class and WORKGROUP (1024 groups): returning atomics on one address
+// serialise in L2 at ~50 ns each, so per-wave appends cost 50 us at 65536 groups.
+__global__ __launch_bounds__(1024) void ball_classes_kernel(long long groups, const int *__restrict__ pts_cnt,
+                                                            int *__restrict__ list, int *__restrict__ count)
+{
+    __shared__ int lcount[CLS_N], lbase[CLS_N];
+    for (long long g0 = (long long)blockIdx.x * 1024; g0 < groups; g0 += (long long)gridDim.x * 1024) {
+        if (threadIdx.x < CLS_N) lcount[threadIdx.x] = 0;
+        __syncthreads();
+        const long long g = g0 + threadIdx.x;
+        int k = -1, pos = 0;
+        if (g < groups) {
+            const int c = pts_cnt[g];
+            k = c <= 1 ? 0 : (c <= 2 ? 1 : (c <= 4 ? 2 : (c <= 8 ? 3 : (c <= 16 ? 4 : 5))));
+            pos = atomicAdd(&lcount[k], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x < CLS_N) lbase[threadIdx.x] = lcount[threadIdx.x] ? atomicAdd(&count[threadIdx.x], lcount[threadIdx.x]) : 0;
+        __syncthreads();
+        if (k >= 0) list[k * groups + lbase[k] + pos] = (int)g;
+        __syncthreads();
+    }
+}
+
 struct ChainArgs {
     long long rows;            // b*m*nsample
     int n, m, ns, c, xyz_first;
@@ -34,6 +181,7 @@ struct ChainArgs {
     const float *w1, *s1, *t1, *w2, *s2, *t2, *w3, *s3, *t3;
     float *out;
     long long ldo;
+    ClsArgs cls;
 };
 
 constexpr int CHAIN_THREADS = 256;
@@ -129,20 +277,21 @@ __global__ __launch_bounds__(CHAIN_THREADS) void sa_chain_kernel(const ChainArgs
     for (int e = tid; e < C3P; e += CHAIN_THREADS) { S3[e] = e < a.c3 ? a.s3[e] : 0.f; T3[e] = e < a.c3 ? a.t3[e] : 0.f; }
     __syncthreads();
 
-    const long long tiles = (a.rows + 31) / 32;
+    ClsTiles ct;
+    cls_setup(a.cls, a.rows / a.ns, a.ns, ct);
+    const long long tiles = ct.start[CLS_N];
     for (long long t = (long long)blockIdx.x * 4 + wave; t < tiles; t += (long long)gridDim.x * 4) {
-        const long long row0 = t * 32;
-        // ---- gather: lane l < 32 builds grouped row row0+l = [feats, xyz-centre] (MSG) or
-        //      [xyz-centre, feats] (SSG), zero-padded to K0P, in the wave's X buffer ------------
+        const ClsTile ti = cls_tile(a.cls, ct, t);
+        // ---- gather: lane l < 32 builds the tile's row l = slot l % G of group l / G, as
+        //      [feats, xyz-centre] (MSG) or [xyz-centre, feats] (SSG), zero-padded to K0P ----------
         if (lane < 32) {
-            const long long r = row0 + lane;
             float v[K0P];
 #pragma unroll
             for (int k = 0; k < K0P; ++k) v[k] = 0.f;
-            if (r < a.rows) {
-                const long long bi = r / ((long long)a.m * a.ns);
-                const long long pi = bi * a.n + a.idx[r];
-                const long long ci = r / a.ns;
+            const long long ci = cls_centroid(ti, ti.gbase + (lane >> ti.lg));
+            if (ci >= 0) {
+                const long long bi = ci / a.m;
+                const long long pi = bi * a.n + a.idx[ci * a.ns + (lane & ((1 << ti.lg) - 1))];
                 const float dx = a.xyz[pi * 3 + 0] - a.new_xyz[ci * 3 + 0];
                 const float dy = a.xyz[pi * 3 + 1] - a.new_xyz[ci * 3 + 1];
                 const float dz = a.xyz[pi * 3 + 2] - a.new_xyz[ci * 3 + 2];
@@ -161,6 +310,8 @@ __global__ __launch_bounds__(CHAIN_THREADS) void sa_chain_kernel(const ChainArgs
             for (int k = 0; k < K0P; k += 4)
                 *reinterpret_cast<f32x4c *>(X + lane * XS + k) = f32x4c{v[k], v[k + 1], v[k + 2], v[k + 3]};
         }
+        int oc[16];                      // output rows of the tile: looked up while the layers run
+        cls_out_rows(ti, kh, oc);
         // wave-private buffer: LDS operations of one wave complete in order, no barrier needed
         f32x16c acc1[C1P / 32];
         chain_layer<K0P, C1P, XS>(X, W1, li, kh, acc1);
@@ -170,27 +321,15 @@ __global__ __launch_bounds__(CHAIN_THREADS) void sa_chain_kernel(const ChainArgs
         chain_store<C2P, XS>(X, S2, T2, li, kh, acc2);
         f32x16c acc3[C3P / 32];
         chain_layer<K2P, C3P, XS>(X, W3, li, kh, acc3);
-        // ---- scale/shift/ReLU + max over nsample (16: two groups per tile, 32: one) -----------
+        // ---- scale/shift/ReLU + max over each group of the tile ---------------------------------
 #pragma unroll
         for (int j = 0; j < C3P / 32; ++j) {
             const int col = j * 32 + li;
             const float sc = S3[col], sh = T3[col];
-            float g0 = 0.f, g1 = 0.f;                 // ReLU output is >= 0
+            float v[16];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) g0 = fmaxf(g0, fmaxf(acc3[j][r] * sc + sh, 0.f));
-#pragma unroll
-            for (int r = 8; r < 16; ++r) g1 = fmaxf(g1, fmaxf(acc3[j][r] * sc + sh, 0.f));
-            g0 = fmaxf(g0, __shfl_xor(g0, 32));
-            g1 = fmaxf(g1, __shfl_xor(g1, 32));
-            if (kh == 0 && col < a.c3) {
-                if (a.ns == 16) {
-                    const long long o0 = row0 / 16;
-                    if (row0 < a.rows) a.out[o0 * a.ldo + col] = g0;
-                    if (row0 + 16 < a.rows) a.out[(o0 + 1) * a.ldo + col] = g1;
-                } else {
-                    if (row0 < a.rows) a.out[(row0 / 32) * a.ldo + col] = fmaxf(g0, g1);
-                }
-            }
+            for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc3[j][r] * sc + sh, 0.f);
+            cls_pool_store(v, ti.lg, oc, col < a.c3, a.out, a.ldo, col);
         }
     }
 }
@@ -216,6 +355,7 @@ struct Chain2Args {
     const float *w2, *s2, *t2, *w3, *s3, *t3;
     float *out;
     long long ldo;
+    ClsArgs cls;
 };
 
 template <int C2P, int NW>
@@ -265,7 +405,9 @@ __global__ __launch_bounds__(NW * 64) void sa_chain2_kernel(const Chain2Args a)
     // One workgroup per CU (the weights fill most of its LDS) owns a contiguous run of tiles; its
     // waves take them one by one from an LDS counter, so a wave that has a SIMD to itself (NW not
     // a multiple of 4) simply takes more of them.
-    const long long tiles = (a.rows + 31) / 32;
+    ClsTiles ct;
+    cls_setup(a.cls, a.rows / a.ns, a.ns, ct);
+    const long long tiles = ct.start[CLS_N];          // virtual tiles over all classes
     const long long per = (tiles + gridDim.x - 1) / gridDim.x;
     const long long t_begin = (long long)blockIdx.x * per;
     const long long t_end = t_begin + per < tiles ? t_begin + per : tiles;
@@ -275,7 +417,8 @@ __global__ __launch_bounds__(NW * 64) void sa_chain2_kernel(const Chain2Args a)
         f32x4c tb[8];
         float rx[8], ry[8], rz[8];
         unsigned ok;             // bit it: the row of pass `it` exists
-        long long t;             // tile, -1 = none left
+        long long t;             // (virtual) tile, -1 = none left
+        ClsTile ti;
     };
     auto grab = [&]() -> long long {
         int tl = 0;
@@ -287,18 +430,19 @@ __global__ __launch_bounds__(NW * 64) void sa_chain2_kernel(const Chain2Args a)
         p.t = grab();
         p.ok = 0;
         if (p.t < 0) return;
-        const long long row0 = p.t * 32;
-        // lane l < 32 resolves row row0+l (point row, relative coordinates)
+        p.ti = cls_tile(a.cls, ct, p.t);
+        // lane l < 32 resolves the tile's row l = slot l % G of group l / G (point row, relative coordinates)
         long long pt = -1;
         float dx = 0.f, dy = 0.f, dz = 0.f;
-        if (lane < 32 && row0 + lane < a.rows) {
-            const long long r = row0 + lane;
-            const long long bi = r / ((long long)a.m * a.ns);
-            pt = bi * a.n + a.idx[r];
-            const long long ci = r / a.ns;
-            dx = a.xyz[pt * 3 + 0] - a.new_xyz[ci * 3 + 0];
-            dy = a.xyz[pt * 3 + 1] - a.new_xyz[ci * 3 + 1];
-            dz = a.xyz[pt * 3 + 2] - a.new_xyz[ci * 3 + 2];
+        if (lane < 32) {
+            const long long ci = cls_centroid(p.ti, p.ti.gbase + (lane >> p.ti.lg));
+            if (ci >= 0) {
+                const long long bi = ci / a.m;
+                pt = bi * a.n + a.idx[ci * a.ns + (lane & ((1 << p.ti.lg) - 1))];
+                dx = a.xyz[pt * 3 + 0] - a.new_xyz[ci * 3 + 0];
+                dy = a.xyz[pt * 3 + 1] - a.new_xyz[ci * 3 + 1];
+                dz = a.xyz[pt * 3 + 2] - a.new_xyz[ci * 3 + 2];
+            }
         }
         const int ptlo = (int)pt, pthi = (int)(pt >> 32);
 #pragma unroll
@@ -321,7 +465,7 @@ __global__ __launch_bounds__(NW * 64) void sa_chain2_kernel(const Chain2Args a)
     Pre cur;
     fetch(cur);
     while (cur.t >= 0) {
-        const long long row0 = cur.t * 32;
+        const ClsTile ti = cur.ti;
         // ---- layer 1 on the VALU, straight into the wave's tile ---------------------------------
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -336,6 +480,8 @@ __global__ __launch_bounds__(NW * 64) void sa_chain2_kernel(const Chain2Args a)
             }
             *reinterpret_cast<f32x4c *>(X + r * XS + pc) = v;
         }
+        int oc[16];                      // output rows of this tile
+        cls_out_rows(ti, kh, oc);
         fetch(cur);              // next tile's loads fly while the matrix cores work on this one
         // ---- layers 2 and 3 on the matrix cores (wave-private tile, no barrier) -----------------
         f32x16c acc2[C2P / 32];
@@ -347,22 +493,10 @@ __global__ __launch_bounds__(NW * 64) void sa_chain2_kernel(const Chain2Args a)
         for (int j = 0; j < C3P / 32; ++j) {
             const int col = j * 32 + li;
             const float sc = S3[col], sh = T3[col];
-            float g0 = 0.f, g1 = 0.f;                 // ReLU output is >= 0
+            float v[16];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) g0 = fmaxf(g0, fmaxf(acc3[j][r] * sc + sh, 0.f));
-#pragma unroll
-            for (int r = 8; r < 16; ++r) g1 = fmaxf(g1, fmaxf(acc3[j][r] * sc + sh, 0.f));
-            g0 = fmaxf(g0, __shfl_xor(g0, 32));
-            g1 = fmaxf(g1, __shfl_xor(g1, 32));
-            if (kh == 0 && col < a.c3) {
-                if (a.ns == 16) {
-                    const long long o0 = row0 / 16;
-                    if (row0 < a.rows) a.out[o0 * a.ldo + col] = g0;
-                    if (row0 + 16 < a.rows) a.out[(o0 + 1) * a.ldo + col] = g1;
-                } else {
-                    if (row0 < a.rows) a.out[(row0 / 32) * a.ldo + col] = fmaxf(g0, g1);
-                }
-            }
+            for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc3[j][r] * sc + sh, 0.f);
+            cls_pool_store(v, ti.lg, oc, col < a.c3, a.out, a.ldo, col);
         }
     }
 }
@@ -373,6 +507,7 @@ static int launch_chain(const ChainArgs &a, hipStream_t st)
     const long long tiles = (a.rows + 31) / 32;
     long long blocks = (tiles + 3) / 4;
     if (blocks > 2048) blocks = 2048;               // persistent-style: weights are loaded once per block
+    if (a.cls.list && blocks > 1024) blocks = 1024; // class lists: usually far fewer tiles than the nominal count
     if (a.c1 <= 16 && a.c2 <= 16)
         hipLaunchKernelGGL((sa_chain_kernel<K0P, 32, 32, C3P, 16, 16>), dim3((unsigned)blocks), dim3(CHAIN_THREADS), 0, st, a);
     else
@@ -383,15 +518,16 @@ static int launch_chain(const ChainArgs &a, hipStream_t st)
 
 }  // namespace prcnn
 
-extern "C" int prcnn_sa_group_mlp3_pool(int b, int n, int m, int nsample, int c, const float *xyz,
-                                        const float *feats, const float *new_xyz, const int *idx,
-                                        int xyz_first, int c1, int c2, int c3, const float *w1,
-                                        const float *s1, const float *t1, const float *w2,
-                                        const float *s2, const float *t2, const float *w3,
-                                        const float *s3, const float *t3, float *out, int64_t ldo,
-                                        prcnn_stream_t stream)
+static int sa_mlp3_pool_impl(int b, int n, int m, int nsample, int c, const float *xyz,
+                             const float *feats, const float *new_xyz, const int *idx,
+                             int xyz_first, int c1, int c2, int c3, const float *w1,
+                             const float *s1, const float *t1, const float *w2,
+                             const float *s2, const float *t2, const float *w3,
+                             const float *s3, const float *t3, float *out, int64_t ldo,
+                             const int *cls_list, const int *cls_count, prcnn_stream_t stream)
 {
     using namespace prcnn;
+    if ((cls_list == nullptr) != (cls_count == nullptr)) return PRCNN_BAD_SHAPE;
     if (b < 0 || n <= 0 || m < 0 || nsample <= 0 || c < 0 || c1 <= 0 || c2 <= 0 || c3 <= 0)
         return PRCNN_BAD_SHAPE;
     if (nsample != 16 && nsample != 32) return PRCNN_UNSUPPORTED;
@@ -407,6 +543,7 @@ extern "C" int prcnn_sa_group_mlp3_pool(int b, int n, int m, int nsample, int c,
     a.c1 = c1; a.c2 = c2; a.c3 = c3;
     a.w1 = w1; a.s1 = s1; a.t1 = t1; a.w2 = w2; a.s2 = s2; a.t2 = t2; a.w3 = w3; a.s3 = s3; a.t3 = t3;
     a.out = out; a.ldo = ldo;
+    a.cls.list = cls_list; a.cls.count = cls_count; a.cls.stride = (long long)b * m;
     hipStream_t st = to_stream(stream);
     const bool k4 = c + 3 <= 4;
     if (c3 <= 32) return k4 ? launch_chain<4, 32>(a, st) : launch_chain<8, 32>(a, st);
@@ -414,15 +551,59 @@ extern "C" int prcnn_sa_group_mlp3_pool(int b, int n, int m, int nsample, int c,
     return k4 ? launch_chain<4, 128>(a, st) : launch_chain<8, 128>(a, st);
 }
 
-extern "C" int prcnn_sa_group_add_mlp2_pool(int b, int n, int m, int nsample, const float *xyz,
-                                            const float *new_xyz, const int *idx, const float *table,
-                                            int64_t ldt, int c1, int c2, int c3, const float *w_xyz,
-                                            const float *s1, const float *t1, const float *w2,
-                                            const float *s2, const float *t2, const float *w3,
-                                            const float *s3, const float *t3, float *out, int64_t ldo,
-                                            prcnn_stream_t stream)
+extern "C" int prcnn_sa_group_mlp3_pool(int b, int n, int m, int nsample, int c, const float *xyz,
+                                        const float *feats, const float *new_xyz, const int *idx,
+                                        int xyz_first, int c1, int c2, int c3, const float *w1,
+                                        const float *s1, const float *t1, const float *w2,
+                                        const float *s2, const float *t2, const float *w3,
+                                        const float *s3, const float *t3, float *out, int64_t ldo,
+                                        prcnn_stream_t stream)
+{
+    return sa_mlp3_pool_impl(b, n, m, nsample, c, xyz, feats, new_xyz, idx, xyz_first, c1, c2, c3, w1, s1, t1, w2, s2,
+                             t2, w3, s3, t3, out, ldo, nullptr, nullptr, stream);
+}
+
+extern "C" int prcnn_sa_group_mlp3_pool_classes(int b, int n, int m, int nsample, int c, const float *xyz,
+                                                const float *feats, const float *new_xyz, const int *idx,
+                                                int xyz_first, int c1, int c2, int c3, const float *w1,
+                                                const float *s1, const float *t1, const float *w2,
+                                                const float *s2, const float *t2, const float *w3,
+                                                const float *s3, const float *t3, float *out, int64_t ldo,
+                                                const int *cls_list, const int *cls_count,
+                                                prcnn_stream_t stream)
+{
+    if (!cls_list || !cls_count) return PRCNN_BAD_SHAPE;
+    return sa_mlp3_pool_impl(b, n, m, nsample, c, xyz, feats, new_xyz, idx, xyz_first, c1, c2, c3, w1, s1, t1, w2, s2,
+                             t2, w3, s3, t3, out, ldo, cls_list, cls_count, stream);
+}
+
+extern "C" int prcnn_ball_count_classes(int64_t groups, const int *pts_cnt, int *cls_list, int *cls_count,
+                                        prcnn_stream_t stream)
+{
+    if (groups < 0) return PRCNN_BAD_SHAPE;
+    if (!cls_count) return PRCNN_BAD_SHAPE;
+    hipStream_t st = to_stream(stream);
+    if (hipMemsetAsync(cls_count, 0, 8 * sizeof(int), st) != hipSuccess) return PRCNN_HIP_ERROR;
+    if (groups == 0) return PRCNN_OK;
+    if (!pts_cnt || !cls_list) return PRCNN_BAD_SHAPE;
+    long long blocks = (groups + 1023) / 1024;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(prcnn::ball_classes_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, (long long)groups, pts_cnt,
+                       cls_list, cls_count);
+    PRCNN_LAUNCH_CHECK();
+    return PRCNN_OK;
+}
+
+static int sa_add_mlp2_pool_impl(int b, int n, int m, int nsample, const float *xyz,
+                                 const float *new_xyz, const int *idx, const float *table,
+                                 int64_t ldt, int c1, int c2, int c3, const float *w_xyz,
+                                 const float *s1, const float *t1, const float *w2,
+                                 const float *s2, const float *t2, const float *w3,
+                                 const float *s3, const float *t3, float *out, int64_t ldo,
+                                 const int *cls_list, const int *cls_count, prcnn_stream_t stream)
 {
     using namespace prcnn;
+    if ((cls_list == nullptr) != (cls_count == nullptr)) return PRCNN_BAD_SHAPE;
     if (b < 0 || n <= 0 || m < 0 || nsample <= 0 || c1 <= 0 || c2 <= 0 || c3 <= 0) return PRCNN_BAD_SHAPE;
     if (nsample != 16 && nsample != 32) return PRCNN_UNSUPPORTED;
     if (c1 > 64 || c2 > 96 || c3 > 128) return PRCNN_UNSUPPORTED;
@@ -436,6 +617,7 @@ extern "C" int prcnn_sa_group_add_mlp2_pool(int b, int n, int m, int nsample, co
     a.table = table; a.ldt = ldt; a.c1 = c1; a.c2 = c2; a.c3 = c3;
     a.wx = w_xyz; a.s1 = s1; a.t1 = t1; a.w2 = w2; a.s2 = s2; a.t2 = t2; a.w3 = w3; a.s3 = s3; a.t3 = t3;
     a.out = out; a.ldo = ldo;
+    a.cls.list = cls_list; a.cls.count = cls_count; a.cls.stride = (long long)b * m;
     hipStream_t st = to_stream(stream);
     const long long tiles = (rows + 31) / 32;
     static const int nw_env = getenv("PRCNN_CHAIN2_NW") ? atoi(getenv("PRCNN_CHAIN2_NW")) : 0;   // tuning aid
@@ -459,4 +641,30 @@ extern "C" int prcnn_sa_group_add_mlp2_pool(int b, int n, int m, int nsample, co
 #undef PRCNN_CHAIN2_LAUNCH
     PRCNN_LAUNCH_CHECK();
     return PRCNN_OK;
+}
+
+extern "C" int prcnn_sa_group_add_mlp2_pool(int b, int n, int m, int nsample, const float *xyz,
+                                            const float *new_xyz, const int *idx, const float *table,
+                                            int64_t ldt, int c1, int c2, int c3, const float *w_xyz,
+                                            const float *s1, const float *t1, const float *w2,
+                                            const float *s2, const float *t2, const float *w3,
+                                            const float *s3, const float *t3, float *out, int64_t ldo,
+                                            prcnn_stream_t stream)
+{
+    return sa_add_mlp2_pool_impl(b, n, m, nsample, xyz, new_xyz, idx, table, ldt, c1, c2, c3, w_xyz, s1, t1, w2, s2, t2,
+                                 w3, s3, t3, out, ldo, nullptr, nullptr, stream);
+}
+
+extern "C" int prcnn_sa_group_add_mlp2_pool_classes(int b, int n, int m, int nsample, const float *xyz,
+                                                    const float *new_xyz, const int *idx, const float *table,
+                                                    int64_t ldt, int c1, int c2, int c3, const float *w_xyz,
+                                                    const float *s1, const float *t1, const float *w2,
+                                                    const float *s2, const float *t2, const float *w3,
+                                                    const float *s3, const float *t3, float *out, int64_t ldo,
+                                                    const int *cls_list, const int *cls_count,
+                                                    prcnn_stream_t stream)
+{
+    if (!cls_list || !cls_count) return PRCNN_BAD_SHAPE;
+    return sa_add_mlp2_pool_impl(b, n, m, nsample, xyz, new_xyz, idx, table, ldt, c1, c2, c3, w_xyz, s1, t1, w2, s2, t2,
+                                 w3, s3, t3, out, ldo, cls_list, cls_count, stream);
 }

@@ -39,11 +39,13 @@ class KernelTimer:
         torch.cuda.synchronize()
         out = {}
         for name, work, s, e in self.records:
-            key = (name, tuple(sorted(work.items()))) if by_shape else name
+            key = (name, tuple(sorted((k, v) for k, v in work.items() if not callable(v)))) if by_shape else name
             d = out.setdefault(key, {"launches": 0, "ms": 0.0})
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
             for k, v in work.items():
+                if callable(v):          # evaluated after the launch finished (data-dependent work)
+                    v = v()
                 if isinstance(v, str):
                     d[k] = v
                 else:
@@ -561,6 +563,95 @@ def sa_group_add_layer(xyz, new_xyz, idx, table, col, cout, w_xyz, scale, shift,
     return out
 
 
+def ball_classes(pts_cnt):
+    """Sort the centroids of one scale into six classes by pts_cnt (<= 1, 2, 4, 8, 16, 32): returns
+    (cls_list (6, b*m) int32, cls_count (8,) int32) for the `classes=` argument of the chain kernels,
+    which then skip the padded copies of a ball's first hit (identical results)."""
+    pts_cnt = _dev(pts_cnt, torch.int32, "ball_classes pts_cnt", 2)
+    groups = pts_cnt.numel()
+    lst = torch.empty((6, max(groups, 1)), dtype=torch.int32, device=pts_cnt.device)
+    cnt = torch.empty((8,), dtype=torch.int32, device=pts_cnt.device)
+    _lib.check(_run("ball_classes", {"bytes": 8 * groups},
+                    lambda: _lib.lib().prcnn_ball_count_classes(groups, _p(pts_cnt), _p(lst), _p(cnt), _stream())),
+               "ball_count_classes")
+    return lst, cnt
+
+
+class CompactRows:
+    """Duplicate-free grouped rows of one scale (prcnn_ball_compact_rows): centroid g owns rows
+    off[g] .. off[g+1]-1, its max(cnt,1) distinct ball slots."""
+
+    def __init__(self, idx, pts_cnt, n):
+        idx = _dev(idx, torch.int32, "compact rows idx", 3)
+        pts_cnt = _dev(pts_cnt, torch.int32, "compact rows pts_cnt", 2)
+        b, m, ns = idx.shape
+        self.groups, self.capacity = b * m, b * m * ns
+        dev = idx.device
+        self.rowpi = torch.empty((max(self.capacity, 1),), dtype=torch.int32, device=dev)
+        self.rowci = torch.empty((max(self.capacity, 1),), dtype=torch.int32, device=dev)
+        self.off = torch.empty((self.groups + 1,), dtype=torch.int32, device=dev)
+        self.rows = torch.empty((1,), dtype=torch.int32, device=dev)
+        _lib.check(_run("compact_rows", {"bytes": self.groups * (8 + 4 * ns)},
+                        lambda: _lib.lib().prcnn_ball_compact_rows(b, n, m, ns, _p(idx), _p(pts_cnt), _p(self.rowpi),
+                                                                   _p(self.rowci), _p(self.off), _p(self.rows), _stream())),
+                   "ball_compact_rows")
+
+    def count(self):
+        return int(self.rows.item())                       # host read-back: instrumentation / tests only
+
+
+def sa_rows_add_layer(cr, xyz, new_xyz, table, col, cout, w_xyz, scale, shift, relu=True, precision=PRECISION_FP32):
+    """sa_group_add_layer over the compacted rows `cr`: returns (capacity, cout), rows past cr.rows unwritten."""
+    xyz = _dev(xyz, torch.float32, "sa_rows_add_layer xyz", 3, 3)
+    new_xyz = _dev(new_xyz, torch.float32, "sa_rows_add_layer new_xyz", 3, 3)
+    table = _dev(table, torch.float32, "sa_rows_add_layer table", 3)
+    w_xyz = _dev(w_xyz, torch.float32, "sa_rows_add_layer w_xyz", 2)
+    scale = _dev(scale, torch.float32, "scale", 1)
+    shift = _dev(shift, torch.float32, "shift", 1)
+    ctab = table.shape[2]
+    if col < 0 or col + cout > ctab or tuple(w_xyz.shape) != (3, cout):
+        raise ValueError("sa_rows_add_layer: table / w_xyz do not hold %d columns at %d" % (cout, col))
+    out = torch.empty((cr.capacity, cout), dtype=torch.float32, device=xyz.device)
+    _lib.check(_run("sa_group_add_layer", {"shape": "rows<=%d N%d compact" % (cr.capacity, cout),
+                                           "bytes": (lambda: cr.count() * (8 + 12 + 8 * cout))},
+                    lambda: _lib.lib().prcnn_sa_rows_add_layer(
+        cr.capacity, _p(cr.rows), _p(cr.rowpi), _p(cr.rowci), _p(xyz), _p(new_xyz), table.data_ptr() + 4 * col, ctab,
+        cout, _p(w_xyz), _p(scale), _p(shift), int(relu), int(precision), _p(out), cout, _stream())),
+        "sa_rows_add_layer")
+    return out
+
+
+def mlp_layer_n(cr, x, w, scale, shift, relu=True, precision=PRECISION_FP32):
+    """mlp_layer over the first cr.rows rows of x (capacity, cin): the count is read on the device."""
+    x = _dev(x, torch.float32, "mlp_layer_n x", 2)
+    w = _dev(w, torch.float32, "mlp_layer_n w", 2)
+    scale = _dev(scale, torch.float32, "scale", 1)
+    shift = _dev(shift, torch.float32, "shift", 1)
+    rows, cin = x.shape
+    cout = w.shape[1]
+    if w.shape[0] != cin or rows != cr.capacity:
+        raise ValueError("mlp_layer_n: x (%d,%d) / w %s / capacity %d do not match" % (rows, cin, tuple(w.shape), cr.capacity))
+    out = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+    _lib.check(_run("mlp_layer", {"shape": "rows<=%d K%d N%d compact" % (rows, cin, cout),
+                                  "flops": (lambda: 2 * cr.count() * cin * cout), "flops_nominal": 2 * rows * cin * cout},
+                    lambda: _lib.lib().prcnn_mlp_layer_n(rows, _p(cr.rows), cin, cout, _p(x), cin, _p(w), _p(scale),
+                                                         _p(shift), int(relu), int(precision), _p(out), cout, _stream())),
+               "mlp_layer_n")
+    return out
+
+
+def segment_max(cr, x, out, out_col=0):
+    """out[g, out_col:out_col+c] = max over the rows of centroid g of x (capacity, c); out (b,m,>=c) or (groups,>=c)."""
+    x = _dev(x, torch.float32, "segment_max x", 2)
+    c = x.shape[1]
+    if not out.is_cuda or out.dtype != torch.float32 or not out.is_contiguous() or out.shape[-1] < out_col + c:
+        raise ValueError("segment_max: out must be a contiguous float32 GPU tensor with >= %d columns" % (out_col + c))
+    _lib.check(_run("segment_max", {"bytes": (lambda: 4 * c * (cr.count() + cr.groups))},
+                    lambda: _lib.lib().prcnn_segment_max(cr.groups, c, _p(x), c, _p(cr.off), out.data_ptr() + 4 * out_col,
+                                                         out.shape[-1], _stream())), "segment_max")
+    return out
+
+
 def sa_chain2_supported(mlp, nsample, precision):
     """Shapes the hoisted-scale chain kernel serves (see prcnn_sa_group_add_mlp2_pool)."""
     return (SA_CHAIN2 and precision == PRECISION_FP32 and len(mlp) == 3 and mlp[0] <= 64 and mlp[1] <= 96
@@ -570,7 +661,7 @@ def sa_chain2_supported(mlp, nsample, precision):
 SA_CHAIN2 = True     # False: hoisted scales always run layer by layer (tests compare the two)
 
 
-def sa_group_add_mlp2_pool(xyz, new_xyz, idx, table, col, w_xyz, layers, out=None, out_col=0):
+def sa_group_add_mlp2_pool(xyz, new_xyz, idx, table, col, w_xyz, layers, out=None, out_col=0, classes=None):
     """A hoisted scale in one launch: table-gather first layer (see sa_group_add_layer) + two
     shared-MLP layers + max over nsample.  layers = [(W, scale, shift)] * 3; only the scale /
     shift of layers[0] are used (its weights are `table` and w_xyz (3,c1)).  Returns (b,m,c3), or
@@ -596,12 +687,19 @@ def sa_group_add_mlp2_pool(xyz, new_xyz, idx, table, col, w_xyz, layers, out=Non
     else:
         res, ldo, optr = out, out.shape[-1], out.data_ptr() + 4 * out_col
     rows = b * m * ns
-    flops = 2 * rows * (3 * c1 + c1 * c2 + c2 * c3)
-    _lib.check(_run("sa_chain2", {"shape": "rows%d N%d-%d-%d pool%d" % (rows, c1, c2, c3, ns), "flops": flops,
+    per_row = 2 * (3 * c1 + c1 * c2 + c2 * c3)
+    # flops = the work the launch executes (padded copies skipped); flops_nominal = SURVEY.md 8d's formula
+    _lib.check(_run("sa_chain2", {"shape": "rows%d N%d-%d-%d pool%d" % (rows, c1, c2, c3, ns),
+                                  "flops": (lambda: per_row * _cls_rows(classes, rows)), "flops_nominal": per_row * rows,
                                   "bytes": rows * (4 + 12 + 4 * c1) + 4 * (rows // ns) * c3},
-                    lambda: _lib.lib().prcnn_sa_group_add_mlp2_pool(
+                    (lambda: _lib.lib().prcnn_sa_group_add_mlp2_pool(
         b, n, m, ns, _p(xyz), _p(new_xyz), _p(idx), table.data_ptr() + 4 * col, ctab, c1, c2, c3, _p(w_xyz),
-        _p(s1), _p(t1), _p(W2), _p(s2), _p(t2), _p(W3), _p(s3), _p(t3), optr, ldo, _stream())),
+        _p(s1), _p(t1), _p(W2), _p(s2), _p(t2), _p(W3), _p(s3), _p(t3), optr, ldo, _stream()))
+                    if classes is None else
+                    (lambda: _lib.lib().prcnn_sa_group_add_mlp2_pool_classes(
+        b, n, m, ns, _p(xyz), _p(new_xyz), _p(idx), table.data_ptr() + 4 * col, ctab, c1, c2, c3, _p(w_xyz),
+        _p(s1), _p(t1), _p(W2), _p(s2), _p(t2), _p(W3), _p(s3), _p(t3), optr, ldo, _p(_cls_check(classes, b * m)[0]),
+        _p(classes[1]), _stream()))),
         "sa_group_add_mlp2_pool")
     return res
 
@@ -612,7 +710,24 @@ def sa_chain_supported(c, mlp, nsample, precision):
             and mlp[1] <= 32 and mlp[2] <= 128 and nsample in (16, 32))
 
 
-def sa_group_mlp3_pool(xyz, feats, new_xyz, idx, layers, xyz_first=False, out=None, out_col=0):
+def _cls_rows(classes, nominal_rows):
+    """Rows a chain kernel evaluates with class lists: whole 32-row tiles of count_k groups of
+    1 << k slots (read back from the device: instrumentation only)."""
+    if classes is None:
+        return nominal_rows
+    c = classes[1][:6].tolist()
+    return sum(32 * ((n * (1 << k) + 31) // 32) for k, n in enumerate(c))
+
+
+def _cls_check(classes, groups):
+    lst, cnt = classes
+    if (not lst.is_cuda or lst.dtype != torch.int32 or not lst.is_contiguous() or tuple(lst.shape) != (6, max(groups, 1))
+            or not cnt.is_cuda or cnt.dtype != torch.int32 or cnt.numel() < 6):
+        raise ValueError("classes must be the (cls_list (6,%d) int32, cls_count int32) pair of ball_classes" % groups)
+    return lst, cnt
+
+
+def sa_group_mlp3_pool(xyz, feats, new_xyz, idx, layers, xyz_first=False, out=None, out_col=0, classes=None):
     """Grouping + three shared-MLP layers + max over nsample in one launch (narrow layers).
     layers = [(W, scale, shift)] * 3.  Returns (b, m, c3), or writes into out[..., out_col:]."""
     xyz = _dev(xyz, torch.float32, "sa_group_mlp3_pool xyz", 3, 3)
@@ -634,12 +749,17 @@ def sa_group_mlp3_pool(xyz, feats, new_xyz, idx, layers, xyz_first=False, out=No
     else:
         res, ldo, optr = out, out.shape[-1], out.data_ptr() + 4 * out_col
     rows = b * m * ns
-    flops = 2 * rows * ((c + 3) * c1 + c1 * c2 + c2 * c3)
+    per_row = 2 * ((c + 3) * c1 + c1 * c2 + c2 * c3)
     _lib.check(_run("sa_chain", {"shape": "rows%d K%d N%d-%d-%d pool%d" % (rows, c + 3, c1, c2, c3, ns),
-                                 "flops": flops, "bytes": rows * (4 + 4 * (c + 3)) + 4 * (rows // ns) * c3},
-                    lambda: _lib.lib().prcnn_sa_group_mlp3_pool(
+                                 "flops": (lambda: per_row * _cls_rows(classes, rows)), "flops_nominal": per_row * rows, "bytes": rows * (4 + 4 * (c + 3)) + 4 * (rows // ns) * c3},
+                    (lambda: _lib.lib().prcnn_sa_group_mlp3_pool(
         b, n, m, ns, c, _p(xyz), _p(feats), _p(new_xyz), _p(idx), int(bool(xyz_first)), c1, c2, c3,
-        _p(W1), _p(s1), _p(t1), _p(W2), _p(s2), _p(t2), _p(W3), _p(s3), _p(t3), optr, ldo, _stream())),
+        _p(W1), _p(s1), _p(t1), _p(W2), _p(s2), _p(t2), _p(W3), _p(s3), _p(t3), optr, ldo, _stream()))
+                    if classes is None else
+                    (lambda: _lib.lib().prcnn_sa_group_mlp3_pool_classes(
+        b, n, m, ns, c, _p(xyz), _p(feats), _p(new_xyz), _p(idx), int(bool(xyz_first)), c1, c2, c3,
+        _p(W1), _p(s1), _p(t1), _p(W2), _p(s2), _p(t2), _p(W3), _p(s3), _p(t3), optr, ldo,
+        _p(_cls_check(classes, b * m)[0]), _p(classes[1]), _stream()))),
         "sa_group_mlp3_pool")
     return res
 

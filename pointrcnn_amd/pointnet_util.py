@@ -76,6 +76,7 @@ class ParamStore(dict):
         return W, s, t
 
 
+SA_DEDUP = True      # chain kernels skip the padded copies of a ball's first hit (ops.ball_classes; same bits)
 SA_SPLIT = True      # hoist the feature half of the first MSG layer out of the grouping (pointnet_sa_module_msg)
 FP_SPLIT = True      # split the first FP convolution around the interpolation (pointnet_fp_module)
 
@@ -178,11 +179,12 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
         if knn:
             _, idx = ops.knn_point(nsample, xyz, new_xyz)            # pointnet_util.py:40-41
         else:
-            idx, _ = ops.query_ball_point(radius, nsample, xyz, new_xyz)
+            idx, pts_cnt = ops.query_ball_point(radius, nsample, xyz, new_xyz)
         if ops.sa_chain_supported(c_feat, mlp, nsample, precision):
             layers = [store.layer('%s/conv%d' % (scope, j), ci, co, bn)
                       for j, (ci, co) in enumerate(zip([c_feat + 3] + list(mlp[:-1]), mlp))]
-            x = ops.sa_group_mlp3_pool(xyz, points, new_xyz, idx, layers, xyz_first=True)
+            x = ops.sa_group_mlp3_pool(xyz, points, new_xyz, idx, layers, xyz_first=True,
+                                       classes=ops.ball_classes(pts_cnt) if SA_DEDUP and not knn else None)
             return new_xyz, x, idx
         W, s, t = store.layer('%s/conv0' % scope, c_feat + 3, mlp[0], bn)
         x = ops.sa_group_mlp_layer(xyz, points, new_xyz, idx, W, s, t, xyz_first=True, relu=True,
@@ -255,7 +257,8 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
             # narrow layers: the whole scale (group, 3 layers, max-pool) is one kernel
             layers = [store.layer('%s/conv%d_%d' % (scope, i, j), ci, co, bn)
                       for j, (ci, co) in enumerate(zip([c_feat + 3] + list(mlp[:-1]), mlp))]
-            ops.sa_group_mlp3_pool(xyz, points, new_xyz, idx, layers, xyz_first=False, out=out, out_col=col)
+            ops.sa_group_mlp3_pool(xyz, points, new_xyz, idx, layers, xyz_first=False, out=out, out_col=col,
+                                   classes=ops.ball_classes(pts_cnt) if SA_DEDUP and pts_cnt is not None else None)
             col += mlp[-1]
             continue
         if fusable and split[i] and ops.sa_chain2_supported(mlp, nsample, precision):
@@ -265,7 +268,21 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
             wx = store.derived('__wx/' + name, lambda: W[c_feat:].contiguous())
             layers = [(W, s, t)] + [store.layer('%s/conv%d_%d' % (scope, i, j), mlp[j - 1], mlp[j], bn)
                                     for j in (1, 2)]
-            ops.sa_group_add_mlp2_pool(xyz, new_xyz, idx, table, tcol[i], wx, layers, out=out, out_col=col)
+            ops.sa_group_add_mlp2_pool(xyz, new_xyz, idx, table, tcol[i], wx, layers, out=out, out_col=col,
+                                       classes=ops.ball_classes(pts_cnt) if SA_DEDUP and pts_cnt is not None else None)
+            col += mlp[-1]
+            continue
+        if fusable and split[i] and SA_DEDUP and pts_cnt is not None and len(mlp) >= 2:
+            # layer by layer over the compacted (duplicate-free) rows, then a max per centroid
+            name = '%s/conv%d_0' % (scope, i)
+            W, s, t = store.layer(name, c_feat + 3, mlp[0], bn)
+            wx = store.derived('__wx/' + name, lambda: W[c_feat:].contiguous())
+            cr = ops.CompactRows(idx, pts_cnt, xyz.shape[1])
+            x = ops.sa_rows_add_layer(cr, xyz, new_xyz, table, tcol[i], mlp[0], wx, s, t, relu=True, precision=precision)
+            for j in range(1, len(mlp)):
+                Wj, sj, tj = store.layer('%s/conv%d_%d' % (scope, i, j), mlp[j - 1], mlp[j], bn)
+                x = ops.mlp_layer_n(cr, x, Wj, sj, tj, relu=True, precision=precision)
+            ops.segment_max(cr, x, out, out_col=col)
             col += mlp[-1]
             continue
         if fusable and split[i]:

@@ -237,6 +237,45 @@ def test_sa_chain2_hoisted_scale_matches_oracle_and_layerwise(cuda, c_feat, npoi
     close(npy(feats), npy(feats_lw), ops.PRECISION_FP32)
 
 
+@pytest.mark.parametrize("radii", [[0.1, 0.5], [0.8, 2.0], [3.0, 8.0]])     # sparse, mixed and full balls
+def test_sa_dedup_classes_are_bit_identical(cuda, radii):
+    """The chain kernels with class lists, and the layer-by-layer path over compacted rows (padded
+    copies of a ball's first hit skipped), against the plain layout: same bits, nsample 16 and 32,
+    every class populated."""
+    rng = np.random.default_rng(31)
+    pc = S.kitti_batch(60, 2, 4096)
+    xyz = dev(pc[:, :, :3].copy(), cuda)
+    new_xyz = ops.gather_point(xyz, ops.farthest_point_sample(777, xyz))
+    seen = np.zeros(6, np.int64)
+    for (idx, cnt), ns in zip(ops.query_ball_point_msg(radii, [16, 32], xyz, new_xyz), (16, 32)):
+        lst, count = ops.ball_classes(cnt)
+        c = npy(count)[:6]
+        seen += c
+        assert c.sum() == cnt.numel()
+        cn = npy(cnt).reshape(-1)
+        bounds = [1, 2, 4, 8, 16, 32]
+        got = np.concatenate([npy(lst)[k, :c[k]] for k in range(6)])
+        assert np.array_equal(np.sort(got), np.arange(cn.size))                  # a partition of the centroids
+        for k in range(6):
+            members = cn[npy(lst)[k, :c[k]]]
+            assert (members <= bounds[k]).all() and (k == 0 or (members > bounds[k - 1]).all())
+    store = PU.ParamStore(seed=5, device=cuda, randomize_bn=True)
+    for c_feat, mlps, scope in ((1, [[16, 16, 32], [32, 32, 64]], 'layer1'), (96, [[64, 64, 128], [64, 96, 128]], 'layer2'),
+                                (256, [[128, 196, 256], [128, 196, 256]], 'layer3')):       # compacted rows, layer by layer
+        pts = dev(rng.standard_normal((2, 4096, c_feat)).astype(np.float32), cuda)
+        outs = []
+        for dedup in (True, False):
+            PU.SA_DEDUP = dedup
+            try:
+                outs.append(PU.pointnet_sa_module_msg(xyz, pts, 777, radii, [16, 32], mlps, False, None, scope=scope,
+                                                      params=store, new_xyz=new_xyz)[1])
+            finally:
+                PU.SA_DEDUP = True
+        assert torch.equal(outs[0], outs[1])
+    if radii[0] == 0.8:
+        assert (seen > 0).all()                                                  # the mixed case exercises every class
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_sa_module_ssg_group_all_and_fp_match_oracle(cuda, fused):
     fr = S.frustum_batch(3, 4, 512, channels=3)

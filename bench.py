@@ -127,6 +127,19 @@ def pipelined_step(pcs_cur, pcs_next, prop, store, precision, cent_cur, cent_nex
     return outs
 
 
+def ball_fill(pcs):
+    """Mean pts_cnt / nsample per SA scale on the bench scenes: the share of grouped rows that are
+    distinct (the rest are the padding copies the duplicate-free kernels skip)."""
+    xyz = pcs[:, :, 0:3].contiguous()
+    out = []
+    for npoint, radii, nsamples, _ in stacks.RPN_SA:
+        new_xyz = ops.gather_point(xyz, ops.farthest_point_sample(npoint, xyz))
+        for (idx, cnt), ns in zip(ops.query_ball_point_msg(radii, nsamples, xyz, new_xyz), nsamples):
+            out.append(round(float(cnt.float().mean().item()) / ns, 3))
+        xyz = new_xyz
+    return out
+
+
 def time_nms(device, n=9000, iters=20):
     boxes, scores = S.nms_boxes(seed=9000, N=n)
     b = torch.as_tensor(boxes).to(device); s = torch.as_tensor(scores).to(device)
@@ -264,6 +277,9 @@ def main():
                     help="pipelined schedule: answer ball queries / three_nn (+ NMS) on the FPS side stream one "
                          "replay ahead instead of in line with the feature phase (measured: 6510 vs 6757 scenes/s "
                          "in line -- the chip is bound by total work / power, not by stream order; kept as an option)")
+    ap.add_argument("--no-dedup", action="store_true",
+                    help="evaluate every padded ball slot (pointnet_util.SA_DEDUP = False): the cost when every ball is "
+                         "full; by default the copies of a ball's first hit that query_ball_point pads with are skipped")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="sample each batch's centroids inside its own step instead of one step ahead")
     args = ap.parse_args()
@@ -271,6 +287,7 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["PRCNN_BENCH_WATCHDOG"]), exit=True)
 
+    PU.SA_DEDUP = not args.no_dedup
     rank, world, local = pdist.init_from_env("cuda")
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
@@ -469,6 +486,7 @@ def main():
                 ("mlp_layer", "rows524288 K96 N128 pool32"): "mlp_kernel<2, 2, 2, 2, false, false, 16> grid_threads=1048576",
                 ("sa_chain", "rows2097152 K4 N32-32-64 pool32"): "sa_chain_kernel<4, 32, 32, 64, 32, 32>",
                 ("sa_chain2", "rows524288 N64-96-128 pool32"): "sa_chain2_kernel<96, 6>",
+                ("mlp_layer", "rows4096 K512 N512 pool1"): "mlp_kernel<4, 1, 1, 2, false, false, 32, false> grid_threads=65536",
             }
             pk = pmc_keys.get((best["kernel"], best["shape"]))
             if pk and precision == 0 and args.batch == BATCH and os.path.exists(pmc_path):
@@ -503,6 +521,7 @@ def main():
                        "batch_per_gpu": args.batch, "points": NPTS, "streams": len(streams),
                        "hip_graph": bool(graphs), "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3),
                        "geometry_streams": bool(args.geo_stream), "fps_one_step_ahead": bool(pipelined),
+                       "duplicate_free_groups": bool(PU.SA_DEDUP), "ball_fill": ball_fill(pcs),
                        "geometry_one_replay_ahead": bool(pipelined and args.geo_ahead), "batches_per_replay": group,
                        "kernel_timing": "HIP events around every launch in an eager, single-stream instrumented "
                                         "pass of the same steps after the timed region",

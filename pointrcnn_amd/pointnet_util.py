@@ -272,7 +272,10 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
                                        classes=ops.ball_classes(pts_cnt) if SA_DEDUP and pts_cnt is not None else None)
             col += mlp[-1]
             continue
-        if fusable and split[i] and SA_DEDUP and pts_cnt is not None and len(mlp) >= 2:
+        # (nsample <= 32 only: with the large, well-filled balls of the Frustum nets -- nsample 64 / 128 on
+        # a few hundred object points -- nothing is saved and the small strided grid of the compacted
+        # launches loses: 2.2 -> 4.0 ms per Frustum batch measured)
+        if fusable and split[i] and SA_DEDUP and pts_cnt is not None and len(mlp) >= 2 and nsample <= 32:
             # layer by layer over the compacted (duplicate-free) rows, then a max per centroid
             name = '%s/conv%d_0' % (scope, i)
             W, s, t = store.layer(name, c_feat + 3, mlp[0], bn)

@@ -39,6 +39,8 @@ def main():
     W4 = [(torch.randn(4, 32, generator=g).mul_(0.3).to(dev),) + (torch.ones(32, device=dev), torch.zeros(32, device=dev)),
           (torch.randn(32, 32, generator=g).mul_(0.2).to(dev),) + (torch.ones(32, device=dev), torch.zeros(32, device=dev)),
           (torch.randn(32, 64, generator=g).mul_(0.2).to(dev),) + (torch.ones(64, device=dev), torch.zeros(64, device=dev))]
+    x512 = torch.randn(b * 256, 512, generator=g).to(dev)          # FP level on 256 points per cloud: 4 launches per step
+    W512 = torch.randn(512, 512, generator=g).mul_(0.05).to(dev)
     x96 = torch.randn(b * 1024 * 32, 96, generator=g).to(dev)     # SA level 2, last layer + max-pool: the step's most expensive MLP launch
     W96 = torch.randn(96, 128, generator=g).mul_(0.1).to(dev)
     (idx1, _), = ops.query_ball_point_msg([0.5], [32], xyz, new1)
@@ -56,6 +58,7 @@ def main():
         "three_nn_interpolate_kernel<4>": b * (12 * 16384 + 12 * 4096) + b * 16384 * 16 * 256,
         "mlp_kernel<2, 2, 2, 2, false, false> rows262144 K260 N128": 4 * (b * 16384 * 260 + 260 * 128 + b * 16384 * 128),
         "mlp_kernel<2, 2, 2, 2, false, false> rows65536 K608 N256": 4 * (b * 4096 * 608 + 608 * 256 + b * 4096 * 256),
+        "mlp_kernel<4, 1, 1, 2, false, false, 32> rows4096 K512 N512": 4 * (b * 256 * 512 + 512 * 512 + b * 256 * 512),
         "mlp_kernel<2, 2, 2, 2, false, false> rows524288 K96 N128 pool32": 4 * (b * 1024 * 32 * 96 + 96 * 128 + b * 1024 * 128),
         "ns_search_kernel<4, true> (culled three_nn + interpolate) n16384 m4096 C256": b * (12 * 16384 + 12 * 4096) + b * 16384 * 16 * 256,
         "bq_culled_kernel<2> n16384 m4096 r0.1/0.5 ns16/32": b * (12 * 16384 + 12 * 4096 + 4 * 4096 * 48 + 8 * 4096),
@@ -70,6 +73,7 @@ def main():
         ops.mlp_layer(x260, W260, *one(128))
         ops.mlp_layer(x608, W608, *one(256))
         ops.mlp_layer(x96, W96, *one(128), pool=32)
+        ops.mlp_layer(x512, W512, *one(512))
         ops.sa_group_mlp3_pool(xyz, feats, new1, idx1, W4)
         ops.sa_group_add_mlp2_pool(new1, new2, idx2, tab, 0, wx, L2)
         ops.sa_group_mlp_layer(new1, f1, new2, idx2, W99, *one(64))

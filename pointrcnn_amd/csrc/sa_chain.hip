@@ -44,107 +44,72 @@ struct ClsArgs {
     long long stride;
 };
 
+// All of this is wave-uniform and lives in scalar registers (readfirstlane); no array is indexed
+// with a run-time value (that would put it in scratch memory).
 struct ClsTiles {
-    long long start[CLS_N + 1];   // first virtual tile of each class
+    int start[CLS_N + 1];         // first virtual tile of each class
     int count[CLS_N];
 };
 
 __device__ __forceinline__ void cls_setup(const ClsArgs &c, long long groups, int ns, ClsTiles &t)
 {
-    long long acc = 0;
+    int acc = 0;
 #pragma unroll
     for (int k = 0; k < CLS_N; ++k) {
         int cnt;
-        if (c.list) cnt = c.count[k];
+        if (c.list) cnt = __builtin_amdgcn_readfirstlane(c.count[k]);
         else cnt = (1 << k) == ns ? (int)groups : 0;
         t.count[k] = cnt;
         t.start[k] = acc;
-        acc += ((long long)cnt + (32 >> k) - 1) >> (5 - k);      // 32 >> k groups per tile
+        acc += (cnt + (32 >> k) - 1) >> (5 - k);                  // 32 >> k groups per tile
     }
     t.start[CLS_N] = acc;
 }
 
 struct ClsTile {
     int lg;                // log2 of the class's group size
-    long long gbase;       // first group (position in the class list) of the tile
+    int gbase;             // first group (position in the class list) of the tile
     int count;             // groups in the class
     const int *lst;        // the class list, or null (identity)
 };
 
-__device__ __forceinline__ ClsTile cls_tile(const ClsArgs &c, const ClsTiles &t, long long vt)
+__device__ __forceinline__ ClsTile cls_tile(const ClsArgs &c, const ClsTiles &t, int vt)
 {
-    int k = 0;
+    int k = 0, st = t.start[0], cn = t.count[0];
 #pragma unroll
-    for (int q = 1; q < CLS_N; ++q) k += vt >= t.start[q] ? 1 : 0;
+    for (int q = 1; q < CLS_N; ++q)
+        if (vt >= t.start[q]) { k = q; st = t.start[q]; cn = t.count[q]; }
     ClsTile r;
     r.lg = k;
-    r.gbase = (vt - t.start[k]) << (5 - k);
-    r.count = t.count[k];
+    r.gbase = (vt - st) << (5 - k);
+    r.count = cn;
     r.lst = c.list ? c.list + (long long)k * c.stride : nullptr;
     return r;
 }
 
 // centroid number (b*m space) of group position g, -1 past the end
-__device__ __forceinline__ long long cls_centroid(const ClsTile &ti, long long g)
+__device__ __forceinline__ int cls_centroid(const ClsTile &ti, int g)
 {
     if (g >= ti.count) return -1;
-    return ti.lst ? (long long)ti.lst[g] : g;
+    return ti.lst ? ti.lst[g] : g;
 }
 
-// Output rows of a tile for this lane half: oc[e] = centroid number that entry e of
-// cls_pool_store writes (-1: none).  Looked up once per tile, before any store (the stores to
-// `out` would otherwise order every later load of the class list behind them).
-__device__ __forceinline__ void cls_out_rows(const ClsTile &ti, int kh, int (&oc)[16])
+// Max over the groups of a 32-row x 32-column block of the tile and store of one value per group
+// and column: out[centroid*ldo + col0 + c].  The block goes through the wave's LDS tile (written
+// in the MFMA C/D layout by the caller: X[row*XS + c]); lane e handles (group e / 32, column
+// e % 32), so the stores of a group are 128 contiguous bytes.  (An in-register version -- G <= 4
+// inside a lane, G >= 8 plus a shfl_xor -- tripled the kernels' registers: 50 -> 140 VGPRs.)
+__device__ __forceinline__ void cls_pool_block(const float *X, int XS, const ClsTile &ti, int lane, int col0,
+                                               int c3, float *out, long long ldo)
 {
-    const int lg = ti.lg;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        long long g = -1;                      // group position of entry e, -1 = entry unused
-        if (lg == 0) g = (e & 3) + 8 * (e >> 2) + 4 * kh;
-        else if (lg == 1) { if (e < 8) g = ((((2 * e) & 3) + 8 * ((2 * e) >> 2) + 4 * kh) >> 1); }
-        else if (lg == 2) { if (e < 4) g = 2 * e + kh; }
-        else if (lg == 3) { if (e < 4 && kh == 0) g = e; }
-        else if (lg == 4) { if (e < 2 && kh == 0) g = e; }
-        else { if (e < 1 && kh == 0) g = 0; }
-        oc[e] = g < 0 ? -1 : (int)cls_centroid(ti, ti.gbase + g);
-    }
-}
-
-// max over the groups of a 32-row tile held in the MFMA C/D layout (v[r]: row (r&3) + 8*(r>>2) +
-// 4*kh, this lane's column) and store of one value per group: out[centroid*ldo + col].
-__device__ __forceinline__ void cls_pool_store(const float (&v)[16], int lg, const int (&oc)[16], bool col_ok,
-                                               float *out, long long ldo, int col)
-{
-    if (lg == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (oc[r] >= 0 && col_ok) out[(long long)oc[r] * ldo + col] = v[r];
-    } else if (lg == 1) {
-#pragma unroll
-        for (int p = 0; p < 8; ++p)
-            if (oc[p] >= 0 && col_ok) out[(long long)oc[p] * ldo + col] = fmaxf(v[2 * p], v[2 * p + 1]);
-    } else {
-        float b4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) b4[q] = fmaxf(fmaxf(v[4 * q], v[4 * q + 1]), fmaxf(v[4 * q + 2], v[4 * q + 3]));
-        if (lg == 2) {                                   // rows 8q + 4kh .. +3 -> group 2q + kh
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (oc[q] >= 0 && col_ok) out[(long long)oc[q] * ldo + col] = b4[q];
-            return;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) b4[q] = fmaxf(b4[q], __shfl_xor(b4[q], 32));     // rows 8q .. 8q+7
-        if (lg == 3) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (oc[q] >= 0 && col_ok) out[(long long)oc[q] * ldo + col] = b4[q];
-        } else if (lg == 4) {
-            if (oc[0] >= 0 && col_ok) out[(long long)oc[0] * ldo + col] = fmaxf(b4[0], b4[1]);
-            if (oc[1] >= 0 && col_ok) out[(long long)oc[1] * ldo + col] = fmaxf(b4[2], b4[3]);
-        } else {
-            if (oc[0] >= 0 && col_ok) out[(long long)oc[0] * ldo + col] = fmaxf(fmaxf(b4[0], b4[1]), fmaxf(b4[2], b4[3]));
-        }
+    const int G = 1 << ti.lg, ngroups = 32 >> ti.lg;
+    for (int e = lane; e < 32 * ngroups; e += 64) {
+        const int g = e >> 5, c = e & 31;
+        const float *xr = X + (g << ti.lg) * XS + c;
+        float mx = xr[0];
+        for (int r = 1; r < G; ++r) mx = fmaxf(mx, xr[r * XS]);
+        const int ci = cls_centroid(ti, ti.gbase + g);
+        if (ci >= 0 && col0 + c < c3) out[(long long)ci * ldo + col0 + c] = mx;
     }
 }
 
@@ -279,8 +244,8 @@ __global__ __launch_bounds__(CHAIN_THREADS) void sa_chain_kernel(const ChainArgs
 
     ClsTiles ct;
     cls_setup(a.cls, a.rows / a.ns, a.ns, ct);
-    const long long tiles = ct.start[CLS_N];
-    for (long long t = (long long)blockIdx.x * 4 + wave; t < tiles; t += (long long)gridDim.x * 4) {
+    const int tiles = ct.start[CLS_N];
+    for (int t = (int)blockIdx.x * 4 + wave; t < tiles; t += (int)gridDim.x * 4) {
         const ClsTile ti = cls_tile(a.cls, ct, t);
         // ---- gather: lane l < 32 builds the tile's row l = slot l % G of group l / G, as
         //      [feats, xyz-centre] (MSG) or [xyz-centre, feats] (SSG), zero-padded to K0P ----------
@@ -288,13 +253,13 @@ __global__ __launch_bounds__(CHAIN_THREADS) void sa_chain_kernel(const ChainArgs
             float v[K0P];
 #pragma unroll
             for (int k = 0; k < K0P; ++k) v[k] = 0.f;
-            const long long ci = cls_centroid(ti, ti.gbase + (lane >> ti.lg));
+            const int ci = cls_centroid(ti, ti.gbase + (lane >> ti.lg));
             if (ci >= 0) {
                 const long long bi = ci / a.m;
-                const long long pi = bi * a.n + a.idx[ci * a.ns + (lane & ((1 << ti.lg) - 1))];
-                const float dx = a.xyz[pi * 3 + 0] - a.new_xyz[ci * 3 + 0];
-                const float dy = a.xyz[pi * 3 + 1] - a.new_xyz[ci * 3 + 1];
-                const float dz = a.xyz[pi * 3 + 2] - a.new_xyz[ci * 3 + 2];
+                const long long pi = bi * a.n + a.idx[(long long)ci * a.ns + (lane & ((1 << ti.lg) - 1))];
+                const float dx = a.xyz[pi * 3 + 0] - a.new_xyz[(long long)ci * 3 + 0];
+                const float dy = a.xyz[pi * 3 + 1] - a.new_xyz[(long long)ci * 3 + 1];
+                const float dz = a.xyz[pi * 3 + 2] - a.new_xyz[(long long)ci * 3 + 2];
                 const int xo = a.xyz_first ? 0 : a.c, fo = a.xyz_first ? 3 : 0;
 #pragma unroll
                 for (int k = 0; k < K0P; ++k) {
@@ -310,8 +275,6 @@ __global__ __launch_bounds__(CHAIN_THREADS) void sa_chain_kernel(const ChainArgs
             for (int k = 0; k < K0P; k += 4)
                 *reinterpret_cast<f32x4c *>(X + lane * XS + k) = f32x4c{v[k], v[k + 1], v[k + 2], v[k + 3]};
         }
-        int oc[16];                      // output rows of the tile: looked up while the layers run
-        cls_out_rows(ti, kh, oc);
         // wave-private buffer: LDS operations of one wave complete in order, no barrier needed
         f32x16c acc1[C1P / 32];
         chain_layer<K0P, C1P, XS>(X, W1, li, kh, acc1);
@@ -321,15 +284,39 @@ __global__ __launch_bounds__(CHAIN_THREADS) void sa_chain_kernel(const ChainArgs
         chain_store<C2P, XS>(X, S2, T2, li, kh, acc2);
         f32x16c acc3[C3P / 32];
         chain_layer<K2P, C3P, XS>(X, W3, li, kh, acc3);
-        // ---- scale/shift/ReLU + max over each group of the tile ---------------------------------
+        // ---- scale/shift/ReLU, then max over each group of the tile, 32 columns at a time ----------
+        if (ti.lg >= 4) {
+            // groups of 16 / 32 rows: registers 0..7 (+ the other lane half) hold rows 0..15
+            const int c0 = cls_centroid(ti, ti.gbase), c1 = ti.lg == 4 ? cls_centroid(ti, ti.gbase + 1) : -1;
 #pragma unroll
-        for (int j = 0; j < C3P / 32; ++j) {
-            const int col = j * 32 + li;
-            const float sc = S3[col], sh = T3[col];
-            float v[16];
+            for (int j = 0; j < C3P / 32; ++j) {
+                const int col = j * 32 + li;
+                const float sc = S3[col], sh = T3[col];
+                float g0 = 0.f, g1 = 0.f;                 // ReLU output is >= 0
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc3[j][r] * sc + sh, 0.f);
-            cls_pool_store(v, ti.lg, oc, col < a.c3, a.out, a.ldo, col);
+                for (int r = 0; r < 8; ++r) g0 = fmaxf(g0, fmaxf(acc3[j][r] * sc + sh, 0.f));
+#pragma unroll
+                for (int r = 8; r < 16; ++r) g1 = fmaxf(g1, fmaxf(acc3[j][r] * sc + sh, 0.f));
+                g0 = fmaxf(g0, __shfl_xor(g0, 32));
+                g1 = fmaxf(g1, __shfl_xor(g1, 32));
+                if (kh == 0 && col < a.c3) {
+                    if (ti.lg == 4) {
+                        if (c0 >= 0) a.out[(long long)c0 * a.ldo + col] = g0;
+                        if (c1 >= 0) a.out[(long long)c1 * a.ldo + col] = g1;
+                    } else if (c0 >= 0) {
+                        a.out[(long long)c0 * a.ldo + col] = fmaxf(g0, g1);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < C3P / 32; ++j) {
+                const float sc = S3[j * 32 + li], sh = T3[j * 32 + li];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    X[((r & 3) + 8 * (r >> 2) + 4 * kh) * XS + li] = fmaxf(acc3[j][r] * sc + sh, 0.f);
+                cls_pool_block(X, XS, ti, lane, j * 32, a.c3, a.out, a.ldo);
+            }
         }
     }
 }
@@ -407,23 +394,23 @@ __global__ __launch_bounds__(NW * 64) void sa_chain2_kernel(const Chain2Args a)
     // a multiple of 4) simply takes more of them.
     ClsTiles ct;
     cls_setup(a.cls, a.rows / a.ns, a.ns, ct);
-    const long long tiles = ct.start[CLS_N];          // virtual tiles over all classes
-    const long long per = (tiles + gridDim.x - 1) / gridDim.x;
-    const long long t_begin = (long long)blockIdx.x * per;
-    const long long t_end = t_begin + per < tiles ? t_begin + per : tiles;
+    const int tiles = ct.start[CLS_N];                // virtual tiles over all classes
+    const int per = (tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t_begin = (int)blockIdx.x * per;
+    const int t_end = t_begin + per < tiles ? t_begin + per : tiles;
     // Layer-1 inputs of a tile are fetched one tile ahead into registers (the table rows come from
     // L2 / HBM: with one workgroup per CU nothing else would hide that latency).
     struct Pre {
         f32x4c tb[8];
         float rx[8], ry[8], rz[8];
         unsigned ok;             // bit it: the row of pass `it` exists
-        long long t;             // (virtual) tile, -1 = none left
+        int t;                   // (virtual) tile, -1 = none left
         ClsTile ti;
     };
-    auto grab = [&]() -> long long {
+    auto grab = [&]() -> int {
         int tl = 0;
         if (lane == 0) tl = atomicAdd(&next_tile, 1);
-        const long long t = t_begin + __builtin_amdgcn_readfirstlane(tl);
+        const int t = t_begin + __builtin_amdgcn_readfirstlane(tl);
         return t < t_end ? t : -1;
     };
     auto fetch = [&](Pre &p) {
@@ -435,13 +422,13 @@ __global__ __launch_bounds__(NW * 64) void sa_chain2_kernel(const Chain2Args a)
         long long pt = -1;
         float dx = 0.f, dy = 0.f, dz = 0.f;
         if (lane < 32) {
-            const long long ci = cls_centroid(p.ti, p.ti.gbase + (lane >> p.ti.lg));
+            const int ci = cls_centroid(p.ti, p.ti.gbase + (lane >> p.ti.lg));
             if (ci >= 0) {
                 const long long bi = ci / a.m;
-                pt = bi * a.n + a.idx[ci * a.ns + (lane & ((1 << p.ti.lg) - 1))];
-                dx = a.xyz[pt * 3 + 0] - a.new_xyz[ci * 3 + 0];
-                dy = a.xyz[pt * 3 + 1] - a.new_xyz[ci * 3 + 1];
-                dz = a.xyz[pt * 3 + 2] - a.new_xyz[ci * 3 + 2];
+                pt = bi * a.n + a.idx[(long long)ci * a.ns + (lane & ((1 << p.ti.lg) - 1))];
+                dx = a.xyz[pt * 3 + 0] - a.new_xyz[(long long)ci * 3 + 0];
+                dy = a.xyz[pt * 3 + 1] - a.new_xyz[(long long)ci * 3 + 1];
+                dz = a.xyz[pt * 3 + 2] - a.new_xyz[(long long)ci * 3 + 2];
             }
         }
         const int ptlo = (int)pt, pthi = (int)(pt >> 32);
@@ -480,8 +467,6 @@ __global__ __launch_bounds__(NW * 64) void sa_chain2_kernel(const Chain2Args a)
             }
             *reinterpret_cast<f32x4c *>(X + r * XS + pc) = v;
         }
-        int oc[16];                      // output rows of this tile
-        cls_out_rows(ti, kh, oc);
         fetch(cur);              // next tile's loads fly while the matrix cores work on this one
         // ---- layers 2 and 3 on the matrix cores (wave-private tile, no barrier) -----------------
         f32x16c acc2[C2P / 32];
@@ -489,14 +474,38 @@ __global__ __launch_bounds__(NW * 64) void sa_chain2_kernel(const Chain2Args a)
         chain_store<C2P, XS>(X, S2, T2, li, kh, acc2);
         f32x16c acc3[C3P / 32];
         chain_layer<C2P, C3P, XS>(X, W3, li, kh, acc3);
+        if (ti.lg >= 4) {
+            // groups of 16 / 32 rows: registers 0..7 (+ the other lane half) hold rows 0..15
+            const int c0 = cls_centroid(ti, ti.gbase), c1 = ti.lg == 4 ? cls_centroid(ti, ti.gbase + 1) : -1;
 #pragma unroll
-        for (int j = 0; j < C3P / 32; ++j) {
-            const int col = j * 32 + li;
-            const float sc = S3[col], sh = T3[col];
-            float v[16];
+            for (int j = 0; j < C3P / 32; ++j) {
+                const int col = j * 32 + li;
+                const float sc = S3[col], sh = T3[col];
+                float g0 = 0.f, g1 = 0.f;                 // ReLU output is >= 0
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = fmaxf(acc3[j][r] * sc + sh, 0.f);
-            cls_pool_store(v, ti.lg, oc, col < a.c3, a.out, a.ldo, col);
+                for (int r = 0; r < 8; ++r) g0 = fmaxf(g0, fmaxf(acc3[j][r] * sc + sh, 0.f));
+#pragma unroll
+                for (int r = 8; r < 16; ++r) g1 = fmaxf(g1, fmaxf(acc3[j][r] * sc + sh, 0.f));
+                g0 = fmaxf(g0, __shfl_xor(g0, 32));
+                g1 = fmaxf(g1, __shfl_xor(g1, 32));
+                if (kh == 0 && col < a.c3) {
+                    if (ti.lg == 4) {
+                        if (c0 >= 0) a.out[(long long)c0 * a.ldo + col] = g0;
+                        if (c1 >= 0) a.out[(long long)c1 * a.ldo + col] = g1;
+                    } else if (c0 >= 0) {
+                        a.out[(long long)c0 * a.ldo + col] = fmaxf(g0, g1);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < C3P / 32; ++j) {
+                const float sc = S3[j * 32 + li], sh = T3[j * 32 + li];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    X[((r & 3) + 8 * (r >> 2) + 4 * kh) * XS + li] = fmaxf(acc3[j][r] * sc + sh, 0.f);
+                cls_pool_block(X, XS, ti, lane, j * 32, a.c3, a.out, a.ldo);
+            }
         }
     }
 }

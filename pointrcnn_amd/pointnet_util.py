@@ -20,6 +20,8 @@ than 'max', mlp2, knn, use_nchw).
 """
 import math
 
+import os
+
 import torch
 
 from . import ops
@@ -76,7 +78,7 @@ class ParamStore(dict):
         return W, s, t
 
 
-SA_DEDUP = True      # chain kernels skip the padded copies of a ball's first hit (ops.ball_classes; same bits)
+SA_DEDUP = os.environ.get("PRCNN_SA_DEDUP", "1") != "0"      # chain kernels skip the padded copies of a ball's first hit (ops.ball_classes; same bits)
 SA_SPLIT = True      # hoist the feature half of the first MSG layer out of the grouping (pointnet_sa_module_msg)
 FP_SPLIT = True      # split the first FP convolution around the interpolation (pointnet_fp_module)
 

@@ -309,6 +309,15 @@ def main():
     # measured later, of 3 batches segfault inside hipGraphLaunch, 1 / 2 / 4 / 5 run (4: thousands of
     # replays over the round).  Only the measured-safe sizes are offered.
     group = {1: 1, 2: 2, 3: 2, 4: 4}.get(max(1, args.fps_group), 5) if pipelined else 1
+    # The live graphs of the process must also stay under ~1600 nodes in total (see below).  With the
+    # duplicate-free launches a batch is ~85 nodes, so units of 4 fit (4 graphs x ~330) but units of 5,
+    # or units of 4 plus the single-batch remainder graphs, do not: when K or W is not a multiple of
+    # the unit, fall back to a unit that divides both, else to units of 2 + single batches.
+    if pipelined:
+        group = min(group, 4)
+        if args.steps % group or args.warmup % group:
+            fits = [g for g in (4, 2) if g <= group and args.steps % g == 0 and args.warmup % g == 0]
+            group = fits[0] if fits else min(group, 2)
     if pipelined:
         # two graphs per stream and unit size (ping-pong over two centroid sets): replay r reads
         # set r%2, which replay r-1 of the same kind on the same stream filled, and fills set

@@ -318,6 +318,10 @@ def main():
         if args.steps % group or args.warmup % group:
             fits = [g for g in (4, 2) if g <= group and args.steps % g == 0 and args.warmup % g == 0]
             group = fits[0] if fits else min(group, 2)
+        # the same budget over the step streams (3 streams x units of 4 = ~2000 nodes: crashed)
+        both_kinds = lambda g: bool(args.steps % g or args.warmup % g)
+        while group > 1 and max(1, args.streams) * 2 * (85 * group + 30 + (115 if both_kinds(group) else 0)) > 1500:
+            group = 2 if group > 2 else 1
     if pipelined:
         # two graphs per stream and unit size (ping-pong over two centroid sets): replay r reads
         # set r%2, which replay r-1 of the same kind on the same stream filled, and fills set
@@ -379,6 +383,7 @@ def main():
                 o = step(pcs, prop, store, precision, geo)
             graphs.append(g); outs.append(o)
 
+    pending = []          # own records of the replays since the last all-gather
     replays = [{group: 0, 1: 0} for _ in streams]      # ping-pong position per unit size (single-graph mode)
 
     def run_steps(k, timer=None):
@@ -407,9 +412,18 @@ def main():
                             flat_a.copy_(flat_b)
                         else:
                             pair[w].replay()
-                        # one collective per replay: the records of its batches travel together
+                        # The records of the replay are copied aside (the graph rewrites its own); ONE
+                        # all-gather moves all of them at the fence that closes the timed region.  A
+                        # collective per replay cost 16 % at one rank (measured, waiting for it or not:
+                        # RCCL's stream is a fifth stream on HIP's four hardware queues, and the event it
+                        # waits on parks in a queue that a step stream shares; more queues are slower
+                        # still: 7.0-7.6k scenes/s at 5 / 6 / 8), and xGMI rewards fewer, larger
+                        # collectives anyway.
                         recs = [rec for _, rec in o]
-                        pdist.all_gather_detections(recs[0] if len(recs) == 1 or not dist.is_initialized() else torch.cat(recs, 0))
+                        if dist.is_initialized():
+                            pending.append(torch.cat(recs, 0) if len(recs) > 1 else recs[0].clone())
+                            if len(pending) >= 256:
+                                flush_records()
                 return
             for i in range(k):
                 j = i % len(streams)
@@ -423,7 +437,16 @@ def main():
         finally:
             ops.set_timer(prev)
 
+    def flush_records():
+        """One all-gather of every record produced since the last flush (ordered by scene id)."""
+        if pending:
+            torch.cuda.synchronize()                    # the copies were made on the step streams
+            gathered = pdist.all_gather_detections(torch.cat(pending, 0))
+            pending.clear()
+            return gathered
+
     def fence():
+        flush_records()
         torch.cuda.synchronize()
         if dist.is_initialized():
             dist.barrier()
@@ -534,7 +557,8 @@ def main():
                        "geometry_one_replay_ahead": bool(pipelined and args.geo_ahead), "batches_per_replay": group,
                        "kernel_timing": "HIP events around every launch in an eager, single-stream instrumented "
                                         "pass of the same steps after the timed region",
-                       "parallelism": "scene-sharded x%d" % world},
+                       "parallelism": "scene-sharded x%d" % world,
+                       "collective": "one RCCL all-gather of all detection records per timed region" if dist.is_initialized() else None},
             "roofline": roof, "kernels": kernels, "fps": fps,
             "nms": {"ms_9000_to_100": round(nms_ms, 4), "kept": nms_keep, "pairs": 9000 * 8999 // 2,
                     "metric": "rotated-NMS ms @9k boxes"},

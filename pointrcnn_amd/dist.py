@@ -102,18 +102,26 @@ def pack_detections(scene_ids, boxes3d, scores, keep, n_keep):
     return rec
 
 
-def all_gather_detections(records):
+def sort_by_scene(gathered):
+    """Rank-major gathered records -> ordered by scene id (column 0)."""
+    return gathered[torch.argsort(gathered[:, 0], stable=True)]
+
+
+def all_gather_detections(records, async_op=False):
     """records (S_local, RECORD_LEN) -> (world*S_local, RECORD_LEN) ordered by scene id.
-    One all-gather; without a process group it is the identity."""
+    One all-gather; without a process group it is the identity.
+    async_op=True: returns (gathered in rank-major order, work handle) without making the current
+    stream wait for the collective; call work.wait() before reading, sort_by_scene() to order."""
     if not dist.is_initialized():
-        return records
+        return (records, None) if async_op else records
     world = dist.get_world_size()
     flat = records.contiguous().reshape(-1)
     out = torch.empty(world * flat.numel(), dtype=records.dtype, device=records.device)
+    if async_op:
+        work = dist.all_gather_into_tensor(out, flat, async_op=True)
+        return out.reshape(world * records.shape[0], records.shape[1]), work
     dist.all_gather_into_tensor(out, flat)          # rank-major concatenation
-    out = out.reshape(world * records.shape[0], records.shape[1])
-    order = torch.argsort(out[:, 0], stable=True)
-    return out[order]
+    return sort_by_scene(out.reshape(world * records.shape[0], records.shape[1]))
 
 
 def unpack_detections(records):

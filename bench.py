@@ -8,8 +8,8 @@ Workload (BASELINE.json configs[2], the config the metric "SA/FP-stack scenes/se
 (16k pts)" is quoted on): the PointRCNN RPN SA+FP stack on a batch of 16 synthetic
 KITTI-shaped scenes x 16384 points per GPU, fused group->shared-MLP->max-pool on the
 matrix cores, followed by the rotated BEV NMS of each scene's 2048 proposals (top 100,
-IoU 0.8: the reference's val/test setting) and -- for N>1 -- ONE all-gather of the
-per-scene detection records.  One "step" = one such batch per rank (weak scaling: every
+IoU 0.8: the reference's val/test setting) and -- for N>1 -- ONE RCCL all-gather of all
+per-scene detection records produced in the timed region, issued at its closing fence.  One "step" = one such batch per rank (weak scaling: every
 rank processes its own 16 scenes per step).  Inputs are resident in HBM before the timed
 region.  Steps are issued as HIP-graph replays of `--fps-group` (default 4) batches each,
 alternating over two streams (a remainder of K mod 4 steps runs as single-batch replays, so

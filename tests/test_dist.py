@@ -37,6 +37,11 @@ def _worker(rank, world, port, n_scenes, q):
     mine = pdist.shard_scenes(n_scenes, r, w)
     rec = _scene_records(mine)
     out = pdist.all_gather_detections(rec)
+    # the asynchronous form (bench.py: records of several replays in one collective, completed later)
+    two = torch.cat([rec, rec + 0.0], 0)
+    raw, work = pdist.all_gather_detections(two, async_op=True)
+    work.wait()
+    assert torch.equal(pdist.sort_by_scene(raw)[::2], out)
     q.put((rank, out.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()

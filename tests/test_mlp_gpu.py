@@ -1,6 +1,6 @@
 """GPU parity: shared-MLP / fused SA / FP layers vs the float64-accumulating oracle.
-Tolerances (north_star): 1e-5 relative for fp32, 1e-2 for bf16 (relative to the
-largest magnitude of the layer's output, plus the same absolute floor)."""
+Tolerances (north_star): 1e-5 relative for fp32, 1e-2 for bf16, checked per element
+(tests/_tol.py: relative to the element, with a floor tied to the tensor's largest magnitude)."""
 import numpy as np
 import pytest
 import torch
@@ -10,7 +10,7 @@ from pointrcnn_amd import ops, pointnet_util as PU, stacks, synthetic as S
 
 pytestmark = pytest.mark.gpu
 
-TOL = {ops.PRECISION_FP32: 1e-5, ops.PRECISION_BF16: 1e-2}
+from _tol import close as _close_elem
 
 
 def dev(a, cuda):
@@ -22,10 +22,9 @@ def npy(t):
 
 
 def close(got, ref, prec):
-    tol = TOL[prec]
-    scale = max(float(np.abs(ref).max()), 1e-6)
-    err = float(np.abs(got - ref).max())
-    assert err <= tol * scale, "max err %g vs %g" % (err, tol * scale)
+    """Elementwise: |err| <= tol * max(|ref|, floor * max|ref|) (tests/_tol.py)."""
+    import inspect
+    _close_elem(got, ref, prec, what=inspect.stack()[1].function)
 
 
 def rand_layer(rng, cin, cout):
@@ -339,9 +338,7 @@ def test_rpn_stack_runs_and_fused_equals_unfused(cuda):
     finally:
         PU.FUSED = True
     close(npy(out), npy(out2), ops.PRECISION_FP32)
-    out3, _ = stacks.rpn_sa_fp_stack(pc, params=store, precision=ops.PRECISION_BF16)
-    ref = npy(out2)
-    assert float(np.abs(npy(out3) - ref).max()) <= 5e-2 * float(np.abs(ref).max())   # 8 layers deep in bf16
+    # (both paths and the bf16 tier against the ORACLE at this size: tests/test_stack_parity_gpu.py)
 
 
 @pytest.mark.parametrize("split", [True, False])

@@ -155,6 +155,18 @@ int prcnn_nms_rotate_batched(int batch, int n, const double *boxes, const double
                              int *n_keep, void *workspace, size_t workspace_bytes,
                              prcnn_stream_t stream);
 
+/* prcnn_nms_rotate without a workspace argument, for callers that CANNOT ALLOCATE device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no
+ * counterpart in the reference.  The workspace is a static device array inside the library
+ * (about 11.3 MB per GPU the library runs on, held until the process ends), so
+ * n <= PRCNN_NMS_NOALLOC_MAX_N; larger n returns PRCNN_UNSUPPORTED (use prcnn_nms_rotate).  The call
+ * allocates and frees nothing and gives the same keep / n_keep as prcnn_nms_rotate.  The stream's
+ * device must be the current device.  All calls on one GPU share the array: calls that overlap
+ * on one GPU (different streams or host threads) race; calls on one stream are ordered. */
+#define PRCNN_NMS_NOALLOC_MAX_N 9216
+int prcnn_nms_rotate_noalloc(int n, const double *boxes, const double *scores, double iou_threshold,
+                             int max_output_size, int64_t *keep, int *n_keep, prcnn_stream_t stream);
+
 /* ---- shared MLP (1x1 conv + folded BN + ReLU) and pooling --------------------------- */
 
 /* One shared-MLP layer, models/tf_util.py:120-185 (conv2d 1x1 + bias + batch_norm +

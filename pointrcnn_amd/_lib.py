@@ -35,6 +35,7 @@ SIGNATURES = {
     "prcnn_three_nn_interpolate": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "prcnn_nms_rotate_workspace_bytes": (_sz, [_i]),
     "prcnn_nms_rotate": (_i, [_i, _vp, _vp, _d, _i, _vp, _vp, _vp, _sz, _vp]),
+    "prcnn_nms_rotate_noalloc": (_i, [_i, _vp, _vp, _d, _i, _vp, _vp, _vp]),
     "prcnn_nms_rotate_batched_workspace_bytes": (_sz, [_i, _i]),
     "prcnn_nms_rotate_batched": (_i, [_i, _i, _vp, _vp, _d, _i, _vp, _vp, _vp, _sz, _vp]),
     "prcnn_mlp_layer": (_i, [_i64, _i, _i, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _i64, _vp]),

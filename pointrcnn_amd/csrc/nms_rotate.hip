@@ -385,9 +385,9 @@ struct NmsLayout {
     size_t rank_off, order_off, rec_off, mask_off, total;
     int words;
 };
-static NmsLayout nms_layout(int batch, int n)
+static constexpr NmsLayout nms_layout(int batch, int n)
 {
-    NmsLayout L;
+    NmsLayout L{};
     L.words = (n + 63) / 64;
     const size_t B = (size_t)batch;
     size_t off = 0;
@@ -657,10 +657,11 @@ extern "C" size_t prcnn_nms_rotate_workspace_bytes(int n)
     return prcnn_nms_rotate_batched_workspace_bytes(1, n);
 }
 
-extern "C" int prcnn_nms_rotate_batched(int batch, int n, const double *boxes, const double *scores,
-                                        double iou_threshold, int max_output_size, int64_t *keep,
-                                        int *n_keep, void *workspace, size_t workspace_bytes,
-                                        prcnn_stream_t stream)
+// The launches of prcnn_nms_rotate_batched on a workspace `ws` of nms_layout(batch, n).total bytes
+// (256-byte aligned); shared by the caller-workspace and the static-scratch entry points.
+static int nms_rotate_run(int batch, int n, const double *boxes, const double *scores, double iou_threshold,
+                          int max_output_size, int64_t *keep, int *n_keep, void *workspace,
+                          size_t workspace_bytes, prcnn_stream_t stream)
 {
     using namespace prcnn;
     if (n < 0 || batch < 0) return PRCNN_BAD_SHAPE;
@@ -713,6 +714,15 @@ extern "C" int prcnn_nms_rotate_batched(int batch, int n, const double *boxes, c
     return PRCNN_OK;
 }
 
+extern "C" int prcnn_nms_rotate_batched(int batch, int n, const double *boxes, const double *scores,
+                                        double iou_threshold, int max_output_size, int64_t *keep,
+                                        int *n_keep, void *workspace, size_t workspace_bytes,
+                                        prcnn_stream_t stream)
+{
+    return nms_rotate_run(batch, n, boxes, scores, iou_threshold, max_output_size, keep, n_keep, workspace,
+                          workspace_bytes, stream);
+}
+
 extern "C" int prcnn_nms_rotate(int n, const double *boxes, const double *scores,
                                 double iou_threshold, int max_output_size, int64_t *keep,
                                 int *n_keep, void *workspace, size_t workspace_bytes,
@@ -720,4 +730,63 @@ extern "C" int prcnn_nms_rotate(int n, const double *boxes, const double *scores
 {
     return prcnn_nms_rotate_batched(1, n, boxes, scores, iou_threshold, max_output_size, keep, n_keep,
                                     workspace, workspace_bytes, stream);
+}
+
+// ---- allocation-free entry point ------------------------------------------------------------
+// prcnn_nms_rotate for callers that cannot allocate (code under HIP graph capture, tight serving
+// loops, harnesses that forbid hipMalloc): the workspace (rank, order, box records, suppression
+// bitmask) is a file-scope device array instead of a caller buffer.  Each GPU the library runs on
+// holds its own copy of the array (PRCNN_NMS_NOALLOC_MAX_N boxes: ~11.3 MB) until the process
+// ends.  In host code the array's NAME is only a stand-in: the device address comes from
+// hipGetSymbolAddress, once per device, with that device current, and only that pointer is ever
+// handed to kernels and memsets.  Calls on one GPU share the array: two calls that overlap on one
+// GPU (different streams or threads) race; calls on one stream are ordered and every call clears
+// what it needs (the rank counters), so stale contents of an earlier, larger call are never read.
+namespace prcnn {
+constexpr int NOALLOC_MAX_N = PRCNN_NMS_NOALLOC_MAX_N;
+constexpr size_t NOALLOC_BYTES = nms_layout(1, NOALLOC_MAX_N).total;
+constexpr int NOALLOC_MAX_DEVICES = 64;
+}  // namespace prcnn
+
+static __device__ __align__(256) unsigned char scratch[prcnn::NOALLOC_BYTES];
+
+#include <mutex>
+static std::mutex g_scratch_mu;
+static void *g_scratch_ptr[prcnn::NOALLOC_MAX_DEVICES] = {};
+
+// device address of `scratch` on the CURRENT device (resolved on the first call per device)
+static int noalloc_scratch(void **out)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        prcnn_note_hip_error((int)e);
+        return PRCNN_HIP_ERROR;
+    }
+    if (dev < 0 || dev >= prcnn::NOALLOC_MAX_DEVICES) return PRCNN_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            prcnn_note_hip_error((int)e);
+            return PRCNN_HIP_ERROR;
+        }
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return PRCNN_OK;
+}
+
+extern "C" int prcnn_nms_rotate_noalloc(int n, const double *boxes, const double *scores,
+                                        double iou_threshold, int max_output_size, int64_t *keep,
+                                        int *n_keep, prcnn_stream_t stream)
+{
+    if (n < 0) return PRCNN_BAD_SHAPE;
+    if (n > prcnn::NOALLOC_MAX_N) return PRCNN_UNSUPPORTED;     // beyond the static scratch: use prcnn_nms_rotate
+    void *ws = nullptr;
+    const int rc = noalloc_scratch(&ws);
+    if (rc != PRCNN_OK) return rc;
+    return nms_rotate_run(1, n, boxes, scores, iou_threshold, max_output_size, keep, n_keep, ws,
+                          prcnn::NOALLOC_BYTES, stream);
 }

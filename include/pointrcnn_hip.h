@@ -134,7 +134,8 @@ int prcnn_three_nn_interpolate(int b, int n, int m, int c, const float *xyz1,
 /* nms_rotate_cpu(boxes, scores, iou_threshold, max_output_size)  utils/nms_rotate.py:39-73
  * boxes (n,5) float64 [x_c, y_c, w, h, theta_deg] exactly as the reference callers build
  * them (dataset/frustum_dataset.py:126-128), scores (n,) float64.  Greedy NMS in
- * descending score order (ties: lower index first), rectangles as OpenCV RotatedRect
+ * descending score order (equal scores: HIGHER index first = scores.argsort(kind='stable')[::-1],
+ * the reference's line :41 with a stable sort; its default sort leaves ties unspecified), rectangles as OpenCV RotatedRect
  * ((b1,b0),(b3,b2),b4), iou = I/(a1+a2-I+1e-7), suppress when iou >= threshold, stop at
  * max_output_size.  keep receives up to min(n,max_output_size) int64 indices into the
  * ORIGINAL arrays, score-descending; *n_keep (device int) the count.  All arithmetic is

@@ -85,7 +85,7 @@ def nms_rotate_cpu(boxes, scores, iou_threshold, max_output_size):
     """utils/nms_rotate.py:39-73, line by line, on the intersection above."""
     boxes = np.asarray(boxes, np.float64)
     keep = []
-    order = np.asarray(scores).argsort()[::-1]
+    order = np.asarray(scores).argsort(kind='stable')[::-1]
     num = boxes.shape[0]
     suppressed = np.zeros((num), dtype=np.int64)
     for _i in range(num):

@@ -184,11 +184,13 @@ def rotated_iou(b1, b2):
 
 def nms_rotate_cpu(boxes, scores, iou_threshold, max_output_size, order=None,
                    return_margin=False):
-    """utils/nms_rotate.py:39-73.  order defaults to scores.argsort()[::-1] (:41)."""
+    """utils/nms_rotate.py:39-73.  order defaults to scores.argsort()[::-1] (:41), with the STABLE
+    sort: NumPy's default (introsort) leaves the order of equal scores unspecified, the stable
+    variant puts them higher index first after the reversal -- the convention the library follows."""
     boxes = np.ascontiguousarray(boxes, np.float64)
     scores = np.asarray(scores)
     if order is None:
-        order = scores.argsort()[::-1]
+        order = scores.argsort(kind='stable')[::-1]
     order = np.ascontiguousarray(order, np.int64)
     num = boxes.shape[0]
     keep = np.empty(max(num, 1), np.int64)

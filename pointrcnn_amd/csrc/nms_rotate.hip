@@ -4,7 +4,10 @@
 // loop around cv2.rotatedRectangleIntersection / convexHull / contourArea).
 // Three launches on the caller's stream, float64 arithmetic throughout (MI355X runs
 // fp64 VALU at half the fp32 rate, and the reference's boxes/scores are float64):
-//   1. rank_kernel     counting sort: rank_i = #{j : s_j > s_i or (s_j == s_i and j < i)}
+//   1. rank_kernel     counting sort: rank_i = #{j : s_j > s_i or (s_j == s_i and j > i)}, i.e. the
+//                      order of `scores.argsort(kind='stable')[::-1]` -- the reference's line :41
+//                      with a stable sort: equal scores come HIGHER index first (NumPy's default
+//                      sort is unstable, so the reference itself leaves ties unspecified)
 //                      (scores tiled through LDS, j range sliced over workgroups, integer
 //                      atomics) + finalize_rank_kernel: order[] and the per-box geometry
 //                      record written at its rank -> everything downstream is in score order.
@@ -38,6 +41,9 @@ constexpr int RANK_TILE = 2048;
 // Partial ranks: block (x = i-block, y = j-slice, z = scene) counts, for its 256 boxes i,
 // the boxes j of its slice that sort before i, and adds the count to rank[i] (zeroed by a
 // hipMemsetAsync ahead of the launch).  Integer atomics: the result is order-independent.
+// HIGH_FIRST: equal scores sort higher index first (rotated NMS, see the header); otherwise lower
+// index first (tf.image.non_max_suppression stand-in, prcnn_nms_aabb_batched).
+template <bool HIGH_FIRST>
 __global__ __launch_bounds__(RANK_THREADS) void rank_kernel(int n, int slice,
                                                             const double *__restrict__ scores_all,
                                                             int *__restrict__ rank_all)
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(RANK_THREADS) void rank_kernel(int n, int slice,
             ss[k] = k < tn ? scores[base + k] : __builtin_nan("");   // NaN never sorts before i
         __syncthreads();
         if (ok) {
-            // j < i only matters for equal scores; split the tile at i to keep the loop branch-free
+            // the index comparison only matters for equal scores
             const int tn4 = (tn + 3) & ~3;
             int c = 0;
 #pragma unroll 2
@@ -66,10 +72,10 @@ __global__ __launch_bounds__(RANK_THREADS) void rank_kernel(int n, int slice,
                 const double2 a = *reinterpret_cast<const double2 *>(&ss[k]);
                 const double2 b = *reinterpret_cast<const double2 *>(&ss[k + 2]);
                 const int g = base + k;
-                c += (a.x > si || (a.x == si && g < i)) ? 1 : 0;
-                c += (a.y > si || (a.y == si && g + 1 < i)) ? 1 : 0;
-                c += (b.x > si || (b.x == si && g + 2 < i)) ? 1 : 0;
-                c += (b.y > si || (b.y == si && g + 3 < i)) ? 1 : 0;
+                c += (a.x > si || (a.x == si && (HIGH_FIRST ? g > i : g < i))) ? 1 : 0;
+                c += (a.y > si || (a.y == si && (HIGH_FIRST ? g + 1 > i : g + 1 < i))) ? 1 : 0;
+                c += (b.x > si || (b.x == si && (HIGH_FIRST ? g + 2 > i : g + 2 < i))) ? 1 : 0;
+                c += (b.y > si || (b.y == si && (HIGH_FIRST ? g + 3 > i : g + 3 < i))) ? 1 : 0;
             }
             cnt += c;
         }
@@ -501,7 +507,7 @@ extern "C" int prcnn_nms_aabb_batched(int batch, int n, const float *boxes, cons
     if (slices < 1) slices = 1;
     const int slice = (((n + slices - 1) / slices) + 3) & ~3;
     slices = (n + slice - 1) / slice;
-    hipLaunchKernelGGL(rank_kernel, dim3(iblocks, slices, batch), dim3(RANK_THREADS), 0, st, n, slice, scores, rank);
+    hipLaunchKernelGGL(rank_kernel<false>, dim3(iblocks, slices, batch), dim3(RANK_THREADS), 0, st, n, slice, scores, rank);
     hipLaunchKernelGGL(aabb_finalize_kernel, dim3(iblocks, 1, batch), dim3(RANK_THREADS), 0, st, n, boxes, rank,
                        order, rec);
     const long long nblk = (long long)L.words * (L.words + 1) / 2;
@@ -693,7 +699,7 @@ static int nms_rotate_run(int batch, int n, const double *boxes, const double *s
     if (slices < 1) slices = 1;
     const int slice = (((n + slices - 1) / slices) + 3) & ~3;
     slices = (n + slice - 1) / slice;
-    hipLaunchKernelGGL(rank_kernel, dim3(iblocks, slices, batch), dim3(RANK_THREADS), 0, st, n, slice,
+    hipLaunchKernelGGL(rank_kernel<true>, dim3(iblocks, slices, batch), dim3(RANK_THREADS), 0, st, n, slice,
                        scores, rank);
     PRCNN_LAUNCH_CHECK();
     hipLaunchKernelGGL(finalize_rank_kernel, dim3(iblocks, 1, batch), dim3(RANK_THREADS), 0, st, n, boxes,

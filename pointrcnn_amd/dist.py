@@ -107,21 +107,51 @@ def sort_by_scene(gathered):
     return gathered[torch.argsort(gathered[:, 0], stable=True)]
 
 
-def all_gather_detections(records, async_op=False):
+SENTINEL_SCENE = -1.0        # scene id of padding records (dropped after the sort)
+MAX_SCENE_ID = 1 << 24       # scene ids travel as float32: exact up to 2**24
+
+
+def pad_records(records, rows):
+    """records (S_local, RECORD_LEN) padded to `rows` rows with sentinel records (scene id -1): every
+    rank must hand the same number of rows to all_gather_into_tensor, and round-robin shards differ by
+    one scene when n_scenes % world != 0."""
+    s = records.shape[0]
+    if s > rows:
+        raise ValueError("pad_records: %d records do not fit %d rows" % (s, rows))
+    if s == rows:
+        return records
+    pad = torch.zeros((rows - s, records.shape[1]), dtype=records.dtype, device=records.device)
+    pad[:, 0] = SENTINEL_SCENE
+    return torch.cat([records, pad], 0)
+
+
+def all_gather_detections(records, async_op=False, n_scenes=None):
     """records (S_local, RECORD_LEN) -> (world*S_local, RECORD_LEN) ordered by scene id.
     One all-gather; without a process group it is the identity.
+    n_scenes: total number of scenes over all ranks when the shards may be unequal
+    (shard_scenes with n_scenes % world != 0): every rank pads to ceil(n_scenes / world) rows with
+    sentinel records, which sort first and are cut off, so (n_scenes, RECORD_LEN) comes back.
+    Without it all ranks must pass the same S_local (checked against the gathered size by torch).
     async_op=True: returns (gathered in rank-major order, work handle) without making the current
-    stream wait for the collective; call work.wait() before reading, sort_by_scene() to order."""
+    stream wait for the collective; call work.wait() before reading, sort_by_scene() to order
+    (and drop the first world*rows - n_scenes rows if n_scenes was given)."""
     if not dist.is_initialized():
         return (records, None) if async_op else records
     world = dist.get_world_size()
+    if n_scenes is not None:
+        if n_scenes > MAX_SCENE_ID:
+            raise ValueError("scene ids travel as float32 and are exact only up to 2**24")
+        records = pad_records(records, (n_scenes + world - 1) // world)
     flat = records.contiguous().reshape(-1)
     out = torch.empty(world * flat.numel(), dtype=records.dtype, device=records.device)
     if async_op:
         work = dist.all_gather_into_tensor(out, flat, async_op=True)
         return out.reshape(world * records.shape[0], records.shape[1]), work
     dist.all_gather_into_tensor(out, flat)          # rank-major concatenation
-    return sort_by_scene(out.reshape(world * records.shape[0], records.shape[1]))
+    res = sort_by_scene(out.reshape(world * records.shape[0], records.shape[1]))
+    if n_scenes is not None:
+        res = res[res.shape[0] - n_scenes:]         # sentinel records (scene id -1) sort first
+    return res
 
 
 def unpack_detections(records):

@@ -23,6 +23,8 @@ def _free_port():
 def _scene_records(scene_ids):
     """Deterministic fake detections of a scene (what NMS + the heads would emit)."""
     S, N = len(scene_ids), 50
+    if S == 0:
+        return torch.empty((0, pdist.RECORD_LEN), dtype=torch.float32)
     boxes = torch.stack([torch.arange(N * 7, dtype=torch.float64).reshape(N, 7) + 1000 * s for s in scene_ids])
     scores = torch.stack([torch.linspace(1, 0, N, dtype=torch.float64) + s for s in scene_ids])
     keep = torch.stack([torch.arange(pdist.MAX_DET) % N for _ in scene_ids]).to(torch.int64)
@@ -36,6 +38,13 @@ def _worker(rank, world, port, n_scenes, q):
     r, w, _ = pdist.init_from_env("cpu")
     mine = pdist.shard_scenes(n_scenes, r, w)
     rec = _scene_records(mine)
+    if n_scenes % w:
+        # unequal shards: every rank pads to ceil(n/world) rows with sentinel records
+        out = pdist.all_gather_detections(rec, n_scenes=n_scenes)
+        q.put((rank, out.numpy().copy()))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     out = pdist.all_gather_detections(rec)
     # the asynchronous form (bench.py: records of several replays in one collective, completed later)
     two = torch.cat([rec, rec + 0.0], 0)
@@ -64,8 +73,13 @@ def test_pack_unpack_roundtrip():
     assert float(rec[0, 2 + 8 * 13:].abs().sum()) == 0.0          # entries past n_keep are zero
 
 
-def test_all_gather_world2_equals_single_process():
-    world, n_scenes = 2, 8
+import pytest
+
+
+@pytest.mark.parametrize("n_scenes", [8, 7, 1])
+def test_all_gather_world2_equals_single_process(n_scenes):
+    """8: equal shards; 7 and 1: n_scenes % world != 0 (one rank holds one scene fewer, or none)."""
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

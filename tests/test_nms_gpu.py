@@ -65,12 +65,20 @@ def test_headline_9000_to_100(cuda):
     assert np.array_equal(again, np.arange(len(got)))
 
 
-def test_score_ties_resolve_to_lower_index(cuda):
+def test_score_ties_follow_reversed_stable_argsort(cuda):
+    """Equal scores (saturated / duplicated confidences): the library orders them higher index first,
+    i.e. scores.argsort(kind='stable')[::-1] -- the reference's line (nms_rotate.py:41) with the
+    stable sort; checked against the oracle's DEFAULT order and against NumPy on a short array."""
     boxes, _ = S.nms_boxes(seed=3, N=200, clusters=4)
     scores = np.repeat(np.linspace(1, 0, 50), 4)
-    order = np.lexsort((np.arange(200), -scores))               # score desc, index asc
-    want = O.nms_rotate_cpu(boxes, scores, 0.5, 100, order=order)
-    assert np.array_equal(nms_rotate_cpu(boxes, scores, 0.5, 100), want)
+    want = O.nms_rotate_cpu(boxes, scores, 0.5, 100)
+    got = nms_rotate_cpu(boxes, scores, 0.5, 100)
+    assert np.array_equal(got, want)
+    assert got[0] == 3                                          # of the four boxes with score 1.0 the last goes first
+    far = np.array([[100.0 * i, 0, 2, 1, 0.] for i in range(12)])                 # disjoint: everything is kept
+    s12 = np.array([.5, .9, .5, .5, .9, .1, .5, .9, .1, .5, .5, .9])
+    assert np.array_equal(nms_rotate_cpu(far, s12, 0.5, 100), s12.argsort(kind='stable')[::-1])
+    assert np.array_equal(nms_rotate_cpu(far, s12, 0.5, 100), O.nms_rotate_cpu(far, s12, 0.5, 100))
 
 
 def test_pack_detections_kernel_equals_host_composition(cuda):

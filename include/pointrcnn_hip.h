@@ -57,9 +57,16 @@ const char *prcnn_last_hip_error_string(void);
  * (32*n floats there).  Here clouds of up to 16384 points never touch it (it may be NULL);
  * larger clouds are split over several cooperating workgroups that exchange one 8-byte
  * record per iteration through `temp`, which must then hold prcnn_fps_temp_bytes(b,n)
- * bytes (it is zeroed by the call; its first int is an error word that stays 0 unless a
- * bounded wait timed out).  With temp == NULL clouds up to 32768 points run on one CU with
- * the min-distance array in LDS; beyond that PRCNN_WORKSPACE is returned. */
+ * bytes (it is zeroed by the call).  Its first int is an ERROR WORD, valid once the stream has
+ * reached the end of the call: 0 = every index was sampled; 1 = a workgroup waited longer than
+ * the bound (~seconds) for its partners -- they were not co-resident, e.g. because another
+ * process filled the GPU -- and the cloud's remaining indices were set to -1.  Callers that
+ * read `out` must check the word (pointrcnn_amd.ops does: `check=True`, or the `fps_error`
+ * tensor attached to the result).  Cooperative launches of one process are ordered one after
+ * the other on the device (two running side by side could starve each other of CUs), except
+ * under stream capture, where the graph's own edges must order them.  With temp == NULL
+ * clouds up to 32768 points run on one CU with the min-distance array in LDS; beyond that
+ * PRCNN_WORKSPACE is returned. */
 int prcnn_farthest_point_sample(int b, int n, int m, const float *inp, float *temp,
                                 int *out, prcnn_stream_t stream);
 size_t prcnn_fps_temp_bytes(int b, int n);

@@ -20,6 +20,7 @@
 // Distances are non-negative floats (or the -1.0f "empty" sentinel), so all min / max /
 // compare run on the int bit patterns (order-preserving, no NaN canonicalisation code).
 #include "common.h"
+#include <mutex>
 
 #ifndef PRCNN_FPS_PROBE
 #define PRCNN_FPS_PROBE 0      // diagnostic builds only: 1 = no coordinate load, 2 = no cross-wave step, 4 = no wave reduce
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(int n, int m, int G, int
                                                         const float *__restrict__ dataset,
                                                         unsigned long long *__restrict__ gran,
                                                         int *__restrict__ err,
-                                                        int *__restrict__ idxs)
+                                                        int *__restrict__ idxs, int spin_limit)
 {
     constexpr int PPT = COOP_PPT, P2 = PPT / 2;
     __shared__ unsigned long long slot[3];
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(int n, int m, int G, int
                     v = __hip_atomic_load(&cgran[(j & 1) * G + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const bool ready = lane >= G || ((unsigned)v & 0x7fffu) == tag;
                 if (__all(ready)) break;
-                if (++spins > (1 << 22)) { timeout = true; break; }
+                if (++spins > spin_limit) { timeout = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
             if (timeout) {
@@ -242,7 +243,11 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(int n, int m, int G, int
         }
         __syncthreads();
         const unsigned long long win = bcast[j & 1];
-        if (win == ~0ull) return;                                        // time-out: leave (uniform)
+        if (win == ~0ull) {                                              // time-out: leave (uniform)
+            if (g == 0)                                                  // no sample from here on: -1, never garbage
+                for (int q = j + tid; q < m; q += 1024) out[q] = -1;
+            return;
+        }
         if (tid == 0) slot[(j + 2) % 3] = 0ull;
         const unsigned k2 = ~(unsigned)win & 0x1ffffu;
         old = (int)((k2 >> 8) + ((k2 & 255u) << 9));
@@ -288,7 +293,7 @@ template <int P2, int NW, bool COOP>
 __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(int n_cloud, int m, const float *__restrict__ dataset,
                                                           int *__restrict__ idxs, int G, int cloud0,
                                                           unsigned long long *__restrict__ gran,
-                                                          int *__restrict__ err, int nc_xcd)
+                                                          int *__restrict__ err, int nc_xcd, int spin_limit)
 {
     constexpr int NT = NW * 64;
     constexpr int CAP = NT * 2 * P2;
@@ -356,7 +361,9 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(int n_cloud, int m,
             }
             int bits[3] = {0, 0, 0};
             float inv = 0.f;
-            if (mx > 0.f) {
+            // (an extent so small that mx / 1024 underflows to zero keeps every point in cell 0: the loop
+            // below would never end on cell == 0)
+            if (mx > 0.f && mx / 1024.f > 0.f) {
                 float cell = mx / 1024.f;
                 for (;;) {
                     int tot = 0;
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(int n_cloud, int m,
                         v = __hip_atomic_load(&cgran[(j & 1) * G + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const bool ready = lane >= G || ((unsigned)v & 0x7fffu) == tag;
                     if (__all(ready)) break;
-                    if (++spins > (1 << 22)) { timeout = true; break; }
+                    if (++spins > spin_limit) { timeout = true; break; }
                 }
                 if (timeout) {
                     if (lane == 0) { atomicExch(err, 1); bcast[j & 1] = ~0ull; }
@@ -559,7 +566,11 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(int n_cloud, int m,
             }
             __syncthreads();
             win = bcast[j & 1];
-            if (win == ~0ull) return;                                    // time-out: leave (uniform)
+            if (win == ~0ull) {                                          // time-out: leave (uniform)
+                if (g == 0)                                              // no sample from here on: -1, never garbage
+                    for (int q = j + tid; q < m; q += NT) out[q] = -1;
+                return;
+            }
         }
         if (tid == 0) slot[(j + 2) % 3] = 0ull;
         const unsigned k2 = ~(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)win) & 0x1ffffu;
@@ -595,6 +606,19 @@ static int launch_fps(int b, int n, int m, const float *inp, int *out, hipStream
     return PRCNN_OK;
 }
 
+// One event per device that chains the cooperative launches of this process (created on first
+// use, never destroyed; hipEventDisableTiming: ordering only).
+static hipEvent_t coop_chain_event()
+{
+    static std::mutex mu;
+    static hipEvent_t ev[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ev[dev] && hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess) ev[dev] = nullptr;
+    return ev[dev];
+}
+
 }  // namespace prcnn
 
 extern "C" size_t prcnn_fps_temp_bytes(int b, int n)
@@ -620,7 +644,7 @@ extern "C" int prcnn_farthest_point_sample(int b, int n, int m, const float *inp
             // 16 waves x 8 buckets; 8 waves x 16 buckets has less fixed cost per iteration but longer
             // update chains per wave: 0.82 vs 0.75 us/iteration measured
             hipLaunchKernelGGL((fps_pruned_kernel<8, 16, false>), dim3(b), dim3(1024), 0, st, n, m, inp, out, 1, 0,
-                               nullptr, nullptr, 0);
+                               nullptr, nullptr, 0, 0);
             PRCNN_LAUNCH_CHECK();
             return PRCNN_OK;
         }
@@ -641,21 +665,38 @@ extern "C" int prcnn_farthest_point_sample(int b, int n, int m, const float *inp
     int *err = reinterpret_cast<int *>(temp);
     unsigned long long *gran = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(temp) + 256);
     const int per_launch = 256 / G;                   // clouds whose workgroups are co-resident
+    // Bound of the per-iteration wait for the other workgroups' granules (polls; ~1 us each).  The
+    // default rides out seconds of other streams' kernels holding CUs; PRCNN_FPS_SPIN_LIMIT (tests)
+    // forces the time-out path: 0 = give up on the first poll that finds a granule missing.
+    int spin_limit = 1 << 22;
+    if (const char *e = getenv("PRCNN_FPS_SPIN_LIMIT")) spin_limit = atoi(e);
+    // Two cooperative launches running side by side could each hold CUs the other's unplaced
+    // workgroups need (every resident workgroup spins on partners that never arrive) until both
+    // time out: launches of this process are therefore chained through one event per device, so a
+    // cooperative launch on one stream starts after the previous one on any stream has finished.
+    // Not done under graph capture (the graph's own edges order its nodes; whoever builds a graph
+    // with two cooperative samplers on parallel branches must join them).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+    hipEvent_t chain = cap == hipStreamCaptureStatusNone ? coop_chain_event() : nullptr;
+    if (chain && hipStreamWaitEvent(st, chain, 0) != hipSuccess) return PRCNN_HIP_ERROR;
     for (int c0 = 0; c0 < b; c0 += per_launch) {
         const int nc = b - c0 < per_launch ? b - c0 : per_launch;
         if (fps_prune_mode() != 0 && m >= 256) {    // long runs: pruned slices (in-workgroup sort pays off)
             static const int xcd = getenv("PRCNN_FPS_XCD") ? atoi(getenv("PRCNN_FPS_XCD")) : 1;   // 0: tuning aid
             if (xcd)
                 hipLaunchKernelGGL((fps_pruned_kernel<8, 16, true>), dim3(8 * G * ((nc + 7) / 8)), dim3(1024), 0, st,
-                                   n, m, inp, out, G, c0, gran, err, nc);
+                                   n, m, inp, out, G, c0, gran, err, nc, spin_limit);
             else
                 hipLaunchKernelGGL((fps_pruned_kernel<8, 16, true>), dim3(nc * G), dim3(1024), 0, st, n, m, inp, out,
-                                   G, c0, gran, err, 0);
+                                   G, c0, gran, err, 0, spin_limit);
         }
         else
-            hipLaunchKernelGGL(fps_coop_kernel, dim3(nc * G), dim3(1024), 0, st, n, m, G, c0, inp, gran, err, out);
+            hipLaunchKernelGGL(fps_coop_kernel, dim3(nc * G), dim3(1024), 0, st, n, m, G, c0, inp, gran, err, out,
+                               spin_limit);
         PRCNN_LAUNCH_CHECK();
     }
+    if (chain && hipEventRecord(chain, st) != hipSuccess) return PRCNN_HIP_ERROR;
     return PRCNN_OK;
 }
 

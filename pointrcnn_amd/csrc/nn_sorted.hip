@@ -76,7 +76,9 @@ __global__ __launch_bounds__(1024) void ns_sort_kernel(int n, int m, const float
         }
         int bits[3] = {0, 0, 0};
         float inv = 0.f;
-        if (mx > 0.f) {
+        // (an extent so small that mx / 1024 underflows to zero keeps every point in cell 0: the loop
+        // below would never end on cell == 0)
+        if (mx > 0.f && mx / 1024.f > 0.f) {
             float cell = mx / 1024.f;                 // at most 10 bits on the longest axis
             for (;;) {
                 int tot = 0;

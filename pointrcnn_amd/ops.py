@@ -93,8 +93,13 @@ def _p(t):
 
 # ---- sampling ---------------------------------------------------------------------------
 
-def farthest_point_sample(npoint, inp):
-    """tf_sampling.py:49-57.  inp (b,n,3) f32 -> (b,npoint) int32."""
+def farthest_point_sample(npoint, inp, check=False):
+    """tf_sampling.py:49-57.  inp (b,n,3) f32 -> (b,npoint) int32.
+    Clouds of more than 16384 points are sampled by several cooperating workgroups, which can
+    fail (bounded wait for a partner that never became resident: see prcnn_farthest_point_sample);
+    the result then carries `fps_error`, a 1-element int32 GPU tensor that is 0 on success (an
+    asynchronous flag: reading it synchronises), and the unsampled tail of the row is -1.
+    check=True reads the flag (one host sync) and raises PointRCNNHipError if it is set."""
     inp = _dev(inp, torch.float32, "FarthestPointSample inp", 3, 3)   # tf_sampling.cpp:105
     b, n, _ = inp.shape
     npoint = int(npoint)
@@ -106,6 +111,12 @@ def farthest_point_sample(npoint, inp):
                              "bytes": b * (12 * n + 4 * npoint)},
                     lambda: L.prcnn_farthest_point_sample(b, n, npoint, _p(inp), _p(temp), _p(out), _stream())),
                "FarthestPointSample")
+    if temp is not None:
+        out.fps_error = temp[:1].view(torch.int32)
+        if check and int(out.fps_error.item()) != 0:
+            raise _lib.PointRCNNHipError(
+                "FarthestPointSample: the cooperating workgroups of a cloud timed out waiting for each other "
+                "(not co-resident: is another process filling the GPU?); the tail of the result is -1")
     return out
 
 

@@ -93,6 +93,54 @@ def test_fps_pruned_cooperative_slices(cuda):
         assert np.array_equal(got, O.farthest_point_sample(m, pts)), n
 
 
+def test_fps_cooperative_error_word_and_forced_timeout(cuda):
+    """The cooperative sampler's error word: 0 after a good run (and absent for clouds that one
+    workgroup samples); with the wait bound forced to zero polls (PRCNN_FPS_SPIN_LIMIT=0) the first
+    exchange times out, the word is set, the unsampled tail is -1 -- never garbage -- and
+    check=True raises.  Both cooperative kernels (plain: m < 256; pruned slices: m >= 256)."""
+    from pointrcnn_amd import _lib
+    pts = dev(S.dense_scene(11, 40000)[None, :, :3].copy(), cuda)
+    small = ops.farthest_point_sample(16, dev(S.dense_scene(11, 4096)[None, :, :3].copy(), cuda))
+    assert not hasattr(small, "fps_error")
+    for m in (64, 300):
+        good = ops.farthest_point_sample(m, pts, check=True)
+        assert int(good.fps_error.item()) == 0 and int(good.min()) >= 0
+        os.environ["PRCNN_FPS_SPIN_LIMIT"] = "0"
+        try:
+            bad = ops.farthest_point_sample(m, pts)
+            torch.cuda.synchronize()
+            assert int(bad.fps_error.item()) == 1
+            b = npy(bad)[0]
+            first_bad = int(np.argmax(b < 0))
+            assert b[0] == 0 and (b < 0).any() and (b[first_bad:] == -1).all()
+            assert np.array_equal(b[:first_bad], npy(good)[0][:first_bad])      # what was sampled is right
+            with pytest.raises(_lib.PointRCNNHipError):
+                ops.farthest_point_sample(m, pts, check=True)
+        finally:
+            del os.environ["PRCNN_FPS_SPIN_LIMIT"]
+        again = ops.farthest_point_sample(m, pts, check=True)                  # the library holds no state
+        assert torch.equal(again, good)
+
+
+def test_fps_cooperative_launches_on_two_streams_do_not_starve_each_other(cuda):
+    """Two cooperative launches issued on different streams (each of 8 workgroups per cloud x 16
+    clouds = half the chip) are chained by the library and both finish with error word 0."""
+    pts = np.stack([S.dense_scene(30 + i, 131072)[:, :3] for i in range(2)])
+    t = dev(np.repeat(pts, 8, axis=0), cuda)                   # 16 clouds
+    s1, s2 = torch.cuda.Stream(device=cuda), torch.cuda.Stream(device=cuda)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        a = ops.farthest_point_sample(260, t)
+    with torch.cuda.stream(s2):
+        b = ops.farthest_point_sample(260, t)
+    torch.cuda.synchronize()
+    assert int(a.fps_error.item()) == 0 and int(b.fps_error.item()) == 0
+    assert torch.equal(a, b)
+    want = O.farthest_point_sample(260, pts)
+    got = npy(a)
+    assert all(np.array_equal(got[i], want[i // 8]) for i in range(16))
+
+
 def test_fps_single_cu_lds_path_without_workspace(cuda):
     """temp == NULL: clouds of 16385..32768 points run on one CU with the min distances in LDS."""
     from pointrcnn_amd import _lib
@@ -341,3 +389,29 @@ def test_three_nn_interpolate_affine_equals_composition(cuda, n, m, c, c1):
         assert float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
     assert not ops.three_nn_interpolate_affine_supported(b, n, 5)
     assert not ops.three_nn_interpolate_affine_supported(1, 1000, 1)
+
+
+def test_searches_and_fps_on_denormal_and_huge_coordinates(cuda):
+    """Coordinates no real scan holds but a buggy caller can pass (this is what round 1's bench did
+    with a freed centroid buffer): int32 data read as floats (denormals: the grid set-up must not
+    divide its way into a zero cell size) and +-1e30 (squared distances overflow to +inf).  The
+    spatially culled searches, the pruned sampler and the brute-force forms finish and equal the
+    oracle bit for bit."""
+    rng = np.random.default_rng(77)
+    n, m = 16384, 1024
+    as_den = lambda a: a.astype(np.int32).view(np.float32)
+    for name, cloud in (("denormal", as_den(rng.integers(0, 5000, (1, n, 3)))),
+                        ("tiny-extent", (1.0 + as_den(rng.integers(0, 3, (1, n, 3)))).astype(np.float32)),
+                        ("huge", rng.choice(np.array([-1e30, 1e30, 0.5, 2.0], np.float32), (1, n, 3)))):
+        cloud = np.ascontiguousarray(cloud, np.float32)
+        t = dev(cloud, cuda)
+        fi = ops.farthest_point_sample(m, t)                               # pruned kernel (n > 4096, m >= 256)
+        assert np.array_equal(npy(fi), O.farthest_point_sample(m, cloud)), name
+        cen = ops.gather_point(t, fi)
+        ncen = npy(cen)
+        for (idx, cnt), r, ns in zip(ops.query_ball_point_msg([0.5, 2.0], [16, 32], t, cen), (0.5, 2.0), (16, 32)):
+            oi, oc = O.query_ball_point(r, ns, cloud, ncen)                # culled search: n*m = 2**24
+            assert np.array_equal(npy(cnt), oc) and np.array_equal(npy(idx), oi), name
+        d, i3 = ops.three_nn(t, cen)                                       # culled search: n*m >= 2**22, m >= 256
+        od, oi3 = O.three_nn(cloud, ncen)
+        assert np.array_equal(npy(d), od) and np.array_equal(npy(i3), oi3), name

@@ -108,8 +108,9 @@ def pipelined_step(pcs_cur, pcs_next, prop, store, precision, cent_cur, cent_nex
     chain's latency is spread over `group` batches.  Returns one (feats, rec) per batch."""
     cur = torch.cuda.current_stream()
     side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        ahead_work(pcs_next, cent_next, group)
+    if os.environ.get("PRCNN_BENCH_PROBE_NO_FPS") != "1":     # probe only: feature phases alone (not a valid bench line)
+        with torch.cuda.stream(side):
+            ahead_work(pcs_next, cent_next, group)
     outs = feature_work(pcs_cur, prop, store, precision, cent_cur, group)
     cur.wait_stream(side)
     for dst, src in zip(cent_cur, cent_next):
@@ -457,8 +458,10 @@ def main():
     ap.add_argument("--geo-stream", action="store_true",
                     help="run each step's FPS chain on a companion stream (helps only single-batch latency)")
     ap.add_argument("--no-graph", action="store_true", help="issue every step eagerly instead of replaying HIP graphs")
-    ap.add_argument("--fps-group", type=int, default=4,
-                    help="batches per graph replay: one FPS chain samples this many upcoming batches at once")
+    ap.add_argument("--fps-group", type=int, default=0,
+                    help="batches per graph replay: one FPS chain samples this many upcoming batches at once "
+                         "(0 = automatic: the size in 4, 5, 6, 3, 8 that deals the K steps evenly over the step "
+                         "streams, so no stream idles while another finishes a last unit; else 4 + eager remainder)")
     ap.add_argument("--no-dedup", action="store_true",
                     help="evaluate every padded ball slot (pointnet_util.SA_DEDUP = False): the cost when every ball is "
                          "full; by default the copies of a ball's first hit that query_ball_point pads with are skipped")
@@ -486,6 +489,9 @@ def main():
     nstreams = max(1, args.streams)
     pipelined = not (args.no_graph or args.no_pipeline or args.geo_stream)
     group = max(1, args.fps_group) if pipelined else 1
+    if pipelined and args.fps_group <= 0:
+        even = [g for g in (4, 5, 6, 3, 8) if args.steps % (g * nstreams) == 0]
+        group = even[0] if even else 4
     ring = torch.zeros((max(args.steps, args.warmup, 1), args.batch, pdist.RECORD_LEN), dtype=torch.float32, device=device)
 
     def make_schedule():

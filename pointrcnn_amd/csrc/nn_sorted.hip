@@ -30,10 +30,16 @@ constexpr int NS_CELLS = 1 << NS_KEY_BITS;
 // coordinates of the three axes fit NS_KEY_BITS bits together (a flat KITTI scene gets
 // e.g. 7+2+6 bits, a cubic cloud 5+5+5), interleaved low bits first (Morton-like order).
 // The order inside a cell is whatever the LDS atomics produce: results do not depend on it.
+// REG: the workgroup's own point set (<= 16384 points) is read from memory ONCE, 16 points per
+// thread with all loads in flight together, and stays in registers for the box, the histogram
+// and the scatter pass (the looping form reads every point three times, one dependent load
+// latency per iteration: 56 us -> see DESIGN.md 4.4).
+template <bool REG>
 __global__ __launch_bounds__(1024) void ns_sort_kernel(int n, int m, const float *__restrict__ xyz1,
                                                        const float *__restrict__ xyz2,
                                                        int *__restrict__ list_q, int *__restrict__ list_k)
 {
+    constexpr int PPT = 16;
     __shared__ int hist[NS_CELLS];
     __shared__ float red[16][6];
     __shared__ float sbox[4];
@@ -42,14 +48,48 @@ __global__ __launch_bounds__(1024) void ns_sort_kernel(int n, int m, const float
     const int bi = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *a = xyz1 + (size_t)bi * n * 3;
     const float *k = xyz2 + (size_t)bi * m * 3;
+    const bool known = blockIdx.x != 0;
+    const float *pts = known ? k : a;                  // the set this workgroup sorts
+    const float *oth = known ? a : k;                  // the other set: joint bounding box only
+    const int np = known ? m : n, no = known ? n : m;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = tid; i < n + m; i += 1024) {
-        const float *p = i < n ? a + (size_t)i * 3 : k + (size_t)(i - n) * 3;
+    float px[REG ? PPT : 1], py[REG ? PPT : 1], pz[REG ? PPT : 1];
+    if (REG) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float v = p[d];
-            lo[d] = fminf(lo[d], v);          // NaN coordinates are ignored by fmin/fmax
-            hi[d] = fmaxf(hi[d], v);
+        for (int q = 0; q < PPT; ++q) {
+            const int i = tid + q * 1024;
+            const bool in = i < np;
+            px[q] = in ? pts[(size_t)i * 3 + 0] : __builtin_nanf("");      // NaN: ignored by fmin / fmax
+            py[q] = in ? pts[(size_t)i * 3 + 1] : __builtin_nanf("");
+            pz[q] = in ? pts[(size_t)i * 3 + 2] : __builtin_nanf("");
+        }
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            lo[0] = fminf(lo[0], px[q]); hi[0] = fmaxf(hi[0], px[q]);
+            lo[1] = fminf(lo[1], py[q]); hi[1] = fmaxf(hi[1], py[q]);
+            lo[2] = fminf(lo[2], pz[q]); hi[2] = fmaxf(hi[2], pz[q]);
+        }
+    }
+    {
+        // box of the other set (REG) or of both sets (looping form): four points per trip, so four
+        // loads per coordinate are in flight
+        const int tot = REG ? no : n + m;
+        for (int i0 = tid; i0 < tot; i0 += 4 * 1024) {
+            float v[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 1024;
+                const float *p = REG ? oth + (size_t)i * 3 : (i < n ? a + (size_t)i * 3 : k + (size_t)(i - n) * 3);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) v[u][d] = i < tot ? p[d] : __builtin_nanf("");
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    lo[d] = fminf(lo[d], v[u][d]);          // NaN coordinates are ignored by fmin/fmax
+                    hi[d] = fmaxf(hi[d], v[u][d]);
+                }
         }
     }
 #pragma unroll
@@ -100,13 +140,9 @@ __global__ __launch_bounds__(1024) void ns_sort_kernel(int n, int m, const float
     __syncthreads();
     const float b0 = sbox[0], b1 = sbox[1], b2 = sbox[2], inv = sbox[3];
     const int t0 = sbits[0], t1 = sbits[1], t2 = sbits[2];
-    const bool known = blockIdx.x != 0;
-    const float *pts = known ? k : a;
-    const int np = known ? m : n;
     int *list = known ? list_k + (size_t)bi * m : list_q + (size_t)bi * n;
-    auto key_of = [&](int i) {
-        const float *p = pts + (size_t)i * 3;
-        const float f0 = (p[0] - b0) * inv, f1 = (p[1] - b1) * inv, f2 = (p[2] - b2) * inv;
+    auto key_xyz = [&](float x, float y, float z) {
+        const float f0 = (x - b0) * inv, f1 = (y - b1) * inv, f2 = (z - b2) * inv;
         const int q0 = f0 > 0.f ? (int)fminf(f0, (float)((1 << t0) - 1)) : 0;      // NaN -> 0
         const int q1 = f1 > 0.f ? (int)fminf(f1, (float)((1 << t1) - 1)) : 0;
         const int q2 = f2 > 0.f ? (int)fminf(f2, (float)((1 << t2) - 1)) : 0;
@@ -118,7 +154,20 @@ __global__ __launch_bounds__(1024) void ns_sort_kernel(int n, int m, const float
         }
         return key;
     };
-    for (int i = tid; i < np; i += 1024) atomicAdd(&hist[key_of(i)], 1);
+    auto key_of = [&](int i) {
+        const float *p = pts + (size_t)i * 3;
+        return key_xyz(p[0], p[1], p[2]);
+    };
+    int keys[REG ? PPT : 1];
+    if (REG) {
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            keys[q] = key_xyz(px[q], py[q], pz[q]);
+            if (tid + q * 1024 < np) atomicAdd(&hist[keys[q]], 1);
+        }
+    } else {
+        for (int i = tid; i < np; i += 1024) atomicAdd(&hist[key_of(i)], 1);
+    }
     __syncthreads();
     // exclusive scan of the histogram in place: 32 consecutive bins per thread
     constexpr int PER = NS_CELLS / 1024;
@@ -140,7 +189,22 @@ __global__ __launch_bounds__(1024) void ns_sort_kernel(int n, int m, const float
         run += h;
     }
     __syncthreads();
-    for (int i = tid; i < np; i += 1024) list[atomicAdd(&hist[key_of(i)], 1)] = i;
+    if (REG) {
+#pragma unroll
+        for (int q = 0; q < PPT; ++q)
+            if (tid + q * 1024 < np) list[atomicAdd(&hist[keys[q]], 1)] = tid + q * 1024;
+    } else {
+        for (int i = tid; i < np; i += 1024) list[atomicAdd(&hist[key_of(i)], 1)] = i;
+    }
+}
+
+static void launch_ns_sort(int b, int n, int m, const float *xyz1, const float *xyz2, int *list_q, int *list_k,
+                           hipStream_t st)
+{
+    if (n <= 16384 && m <= 16384)
+        hipLaunchKernelGGL(ns_sort_kernel<true>, dim3(2, b), dim3(1024), 0, st, n, m, xyz1, xyz2, list_q, list_k);
+    else
+        hipLaunchKernelGGL(ns_sort_kernel<false>, dim3(2, b), dim3(1024), 0, st, n, m, xyz1, xyz2, list_q, list_k);
 }
 
 // ---- 3. sorted known points (x, y, z, original index) and their tile boxes -----------------
@@ -379,7 +443,7 @@ static int ns_run(int b, int n, int m, int c, const float *xyz1, const float *xy
     if (!ws || ws_bytes < w.bytes) return PRCNN_WORKSPACE;
     if (((uintptr_t)ws & 255) != 0) return PRCNN_BAD_ARG;
     const int tiles = (m + 63) / 64;
-    hipLaunchKernelGGL(ns_sort_kernel, dim3(2, b), dim3(1024), 0, st, n, m, xyz1, xyz2, w.list_q, w.list_k);
+    launch_ns_sort(b, n, m, xyz1, xyz2, w.list_q, w.list_k, st);
     const long long total_tiles = (long long)b * tiles;
     hipLaunchKernelGGL(ns_tile_kernel<true>, dim3((unsigned)((total_tiles + 3) / 4)), dim3(256), 0, st, m, tiles,
                        total_tiles, xyz2, w.list_k, w.kp, w.tb);
@@ -540,7 +604,7 @@ static int bq_run(int b, int n, int m, int nscales, const BallScales &sc, const 
     if (!ws || ws_bytes < w.bytes) return PRCNN_WORKSPACE;
     if (((uintptr_t)ws & 255) != 0) return PRCNN_BAD_ARG;
     const int tiles = (n + 63) / 64;
-    hipLaunchKernelGGL(ns_sort_kernel, dim3(2, b), dim3(1024), 0, st, m, n, xyz2, xyz1, w.list_q, w.list_k);
+    launch_ns_sort(b, m, n, xyz2, xyz1, w.list_q, w.list_k, st);
     const long long total_tiles = (long long)b * tiles;
     hipLaunchKernelGGL(ns_tile_kernel<false>, dim3((unsigned)((total_tiles + 3) / 4)), dim3(256), 0, st, n, tiles,
                        total_tiles, xyz1, w.list_k, w.kp, w.tb);

@@ -47,11 +47,33 @@ def test_edge_cases(cuda):
 
 
 @pytest.mark.parametrize("N,thr,mx", [(2048, 0.85, 300), (2048, 0.8, 100), (2048, 0.7, 10), (2048, 0.7, 300),
-                                      (777, 0.3, 1000), (130, 0.5, 64)])
+                                      (777, 0.3, 1000), (130, 0.5, 64),
+                                      # around the 512-rank head of the two-stage evaluation: the head ends the
+                                      # sweep (max_out reached at / just before its last rank), just fails to, or
+                                      # holds every box
+                                      (513, 0.95, 512), (1024, 0.99, 511), (1024, 0.99, 512), (1024, 0.99, 513),
+                                      (512, 0.5, 512), (511, 0.9, 1000), (3000, 0.6, 400)])
 def test_reference_scale(cuda, N, thr, mx):
     boxes, scores = S.nms_boxes(seed=N, N=N, clusters=max(2, N // 60))
     got, want = _check(boxes, scores, thr, mx)
     assert np.array_equal(got, want)
+
+
+def test_batched_frames_finish_in_head_or_tail_independently(cuda):
+    """prcnn_nms_rotate_batched on frames of very different density: sparse frames end inside the
+    512-rank head (their done flag silences the tail launches), dense ones (2 clusters: almost
+    everything suppressed) need the full mask -- every frame equals its own single-frame oracle."""
+    from pointrcnn_amd.nms_rotate import nms_rotate_batched
+    N = 1500
+    frames = [S.nms_boxes(seed=50 + i, N=N, clusters=c) for i, c in enumerate((300, 2, 40, 1, 700, 3))]
+    boxes = torch.as_tensor(np.stack([f[0] for f in frames])).to(cuda)
+    scores = torch.as_tensor(np.stack([f[1] for f in frames])).to(cuda)
+    for thr, mx in ((0.8, 100), (0.5, 300), (0.3, 1500)):
+        keep, nk = nms_rotate_batched(boxes, scores, thr, mx)
+        keep, nk = keep.cpu().numpy(), nk.cpu().numpy()
+        for i, (b, s) in enumerate(frames):
+            want = O.nms_rotate_cpu(b, s, thr, mx)
+            assert nk[i] == len(want) and np.array_equal(keep[i, :nk[i]], want), (thr, mx, i)
 
 
 def test_headline_9000_to_100(cuda):

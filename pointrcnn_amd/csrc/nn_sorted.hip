@@ -40,7 +40,7 @@ __global__ __launch_bounds__(1024) void ns_sort_kernel(int n, int m, const float
                                                        int *__restrict__ list_q, int *__restrict__ list_k)
 {
     constexpr int PPT = 16;
-    __shared__ int hist[NS_CELLS];
+    __shared__ __attribute__((aligned(16))) int hist[NS_CELLS];
     __shared__ float red[16][6];
     __shared__ float sbox[4];
     __shared__ int sbits[3];
@@ -141,18 +141,27 @@ __global__ __launch_bounds__(1024) void ns_sort_kernel(int n, int m, const float
     const float b0 = sbox[0], b1 = sbox[1], b2 = sbox[2], inv = sbox[3];
     const int t0 = sbits[0], t1 = sbits[1], t2 = sbits[2];
     int *list = known ? list_k + (size_t)bi * m : list_q + (size_t)bi * n;
+    // bit-interleaved key through three tables (one per axis: the cell coordinate's bits spread to
+    // their key positions; built once by the workgroup, sharing the histogram's barrier): the
+    // 30-step interleave per point was the kernel's largest cost
+    __shared__ int spread[3][1024];
+    {
+        const int q = tid;                                   // 1024 threads: one table entry per axis each
+        int k0 = 0, k1 = 0, k2 = 0, pos = 0;
+        for (int lv = 0; lv < 10; ++lv) {
+            if (lv < t0) { k0 |= ((q >> lv) & 1) << pos; ++pos; }
+            if (lv < t1) { k1 |= ((q >> lv) & 1) << pos; ++pos; }
+            if (lv < t2) { k2 |= ((q >> lv) & 1) << pos; ++pos; }
+        }
+        spread[0][q] = k0; spread[1][q] = k1; spread[2][q] = k2;
+    }
+    __syncthreads();
     auto key_xyz = [&](float x, float y, float z) {
         const float f0 = (x - b0) * inv, f1 = (y - b1) * inv, f2 = (z - b2) * inv;
         const int q0 = f0 > 0.f ? (int)fminf(f0, (float)((1 << t0) - 1)) : 0;      // NaN -> 0
         const int q1 = f1 > 0.f ? (int)fminf(f1, (float)((1 << t1) - 1)) : 0;
         const int q2 = f2 > 0.f ? (int)fminf(f2, (float)((1 << t2) - 1)) : 0;
-        int key = 0, pos = 0;
-        for (int lv = 0; lv < 10; ++lv) {
-            if (lv < t0) { key |= ((q0 >> lv) & 1) << pos; ++pos; }
-            if (lv < t1) { key |= ((q1 >> lv) & 1) << pos; ++pos; }
-            if (lv < t2) { key |= ((q2 >> lv) & 1) << pos; ++pos; }
-        }
-        return key;
+        return spread[0][q0] | spread[1][q1] | spread[2][q2];
     };
     auto key_of = [&](int i) {
         const float *p = pts + (size_t)i * 3;
@@ -169,10 +178,17 @@ __global__ __launch_bounds__(1024) void ns_sort_kernel(int n, int m, const float
         for (int i = tid; i < np; i += 1024) atomicAdd(&hist[key_of(i)], 1);
     }
     __syncthreads();
-    // exclusive scan of the histogram in place: 32 consecutive bins per thread
+    // exclusive scan of the histogram in place: 32 consecutive bins per thread, moved as 8 x 16 bytes
     constexpr int PER = NS_CELLS / 1024;
+    static_assert(PER == 32, "scan layout");
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 hv[PER / 4];
     int sum = 0;
-    for (int c = 0; c < PER; ++c) sum += hist[tid * PER + c];
+#pragma unroll
+    for (int c = 0; c < PER / 4; ++c) {
+        hv[c] = *reinterpret_cast<const i32x4 *>(&hist[tid * PER + c * 4]);
+        sum += hv[c][0] + hv[c][1] + hv[c][2] + hv[c][3];
+    }
     int incl = sum;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -183,10 +199,12 @@ __global__ __launch_bounds__(1024) void ns_sort_kernel(int n, int m, const float
     __syncthreads();
     int run = incl - sum;
     for (int w = 0; w < wave; ++w) run += wsum[w];
-    for (int c = 0; c < PER; ++c) {
-        const int h = hist[tid * PER + c];
-        hist[tid * PER + c] = run;
-        run += h;
+#pragma unroll
+    for (int c = 0; c < PER / 4; ++c) {
+        i32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = run; run += hv[c][e]; }
+        *reinterpret_cast<i32x4 *>(&hist[tid * PER + c * 4]) = o;
     }
     __syncthreads();
     if (REG) {

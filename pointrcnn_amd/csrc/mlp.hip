@@ -597,46 +597,52 @@ extern "C" int prcnn_max_pool(int64_t groups, int nsample, int c, const float *x
 // ---- compacted (duplicate-free) grouped rows ------------------------------------------------
 namespace prcnn {
 
-// rows of centroid g = its max(cnt,1) distinct slots; off[g] = first row.  One workgroup walks the
-// centroids in chunks of 1024 with a running offset (b*m is a few thousand where this is used).
+// rows of centroid g = its max(cnt,1) distinct slots; off[g] = first row.  Workgroup j owns the
+// centroids [1024 j, 1024 j + 1024): it first adds up the row counts of all centroids before its
+// chunk (coalesced reads of pts_cnt, 1024 lanes: cheaper than any cross-workgroup hand-off at the
+// sizes in use, b*m <= 65536), then scans its own chunk.
 __global__ __launch_bounds__(1024) void compact_rows_kernel(long long groups, int n, int m, int ns,
                                                             const int *__restrict__ idx, const int *__restrict__ pts_cnt,
                                                             int *__restrict__ rowpi, int *__restrict__ rowci,
                                                             int *__restrict__ off, int *__restrict__ rows_dev)
 {
     __shared__ int wsum[16];
-    __shared__ int carry;
+    __shared__ int wpre[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (long long g0 = 0; g0 < groups; g0 += 1024) {
-        const long long g = g0 + tid;
-        int c = 0;
-        if (g < groups) { c = pts_cnt[g]; c = c < 1 ? 1 : (c > ns ? ns : c); }
-        int incl = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(incl, d);
-            if (lane >= d) incl += t;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int base = carry;
-        for (int w = 0; w < wave; ++w) base += wsum[w];
-        const int first = base + incl - c;
-        if (g < groups) {
-            off[g] = first;
-            const long long bi = g / m;
-            for (int k = 0; k < c; ++k) {
-                rowpi[first + k] = (int)(bi * n + idx[g * ns + k]);
-                rowci[first + k] = (int)g;
-            }
-        }
-        __syncthreads();
-        if (tid == 1023) carry = base + incl;
-        __syncthreads();
+    const long long g0 = (long long)blockIdx.x * 1024;
+    if (groups == 0) {
+        if (tid == 0) { off[0] = 0; *rows_dev = 0; }
+        return;
     }
-    if (tid == 0) { off[groups] = carry; *rows_dev = carry; }
+    auto rows_of = [&](long long g) { const int c = pts_cnt[g]; return c < 1 ? 1 : (c > ns ? ns : c); };
+    int pre = 0;
+    for (long long g = tid; g < g0; g += 1024) pre += rows_of(g);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) pre += __shfl_xor(pre, d);
+    const long long g = g0 + tid;
+    const int c = g < groups ? rows_of(g) : 0;
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    if (lane == 0) wpre[wave] = pre;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < 16; ++w) base += wpre[w];
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    const int first = base + incl - c;
+    if (g < groups) {
+        off[g] = first;
+        const long long bi = g / m;
+        for (int k = 0; k < c; ++k) {
+            rowpi[first + k] = (int)(bi * n + idx[g * ns + k]);
+            rowci[first + k] = (int)g;
+        }
+        if (g == groups - 1) { off[groups] = first + c; *rows_dev = first + c; }
+    }
 }
 
 // out[g][:] = max over rows off[g] .. off[g+1]-1 of x (one wave per group, lanes over columns)
@@ -665,7 +671,7 @@ extern "C" int prcnn_ball_compact_rows(int b, int n, int m, int nsample, const i
     const long long groups = (long long)b * m;
     if (groups * nsample > 0x7fffffffLL || (long long)b * n > 0x7fffffffLL) return PRCNN_UNSUPPORTED;
     if (groups > 0 && (!idx || !pts_cnt || !rowpi || !rowci)) return PRCNN_BAD_SHAPE;
-    hipLaunchKernelGGL(prcnn::compact_rows_kernel, dim3(1), dim3(1024), 0, to_stream(stream), groups, n, m, nsample, idx,
+    hipLaunchKernelGGL(prcnn::compact_rows_kernel, dim3((unsigned)(groups > 0 ? (groups + 1023) / 1024 : 1)), dim3(1024), 0, to_stream(stream), groups, n, m, nsample, idx,
                        pts_cnt, rowpi, rowci, off, rows_dev);
     PRCNN_LAUNCH_CHECK();
     return PRCNN_OK;

@@ -665,7 +665,7 @@ def segment_max(cr, x, out, out_col=0):
 
 def sa_chain2_supported(mlp, nsample, precision):
     """Shapes the hoisted-scale chain kernel serves (see prcnn_sa_group_add_mlp2_pool)."""
-    return (SA_CHAIN2 and precision == PRECISION_FP32 and len(mlp) == 3 and mlp[0] <= 64 and mlp[1] <= 96
+    return (SA_CHAIN2 and len(mlp) == 3 and mlp[0] <= 64 and mlp[1] <= 96
             and mlp[2] <= 128 and nsample in (16, 32))
 
 
@@ -717,7 +717,7 @@ def sa_group_add_mlp2_pool(xyz, new_xyz, idx, table, col, w_xyz, layers, out=Non
 
 def sa_chain_supported(c, mlp, nsample, precision):
     """Shapes the fully fused set-abstraction kernel serves (see prcnn_sa_group_mlp3_pool)."""
-    return (precision == PRECISION_FP32 and len(mlp) == 3 and c + 3 <= 8 and mlp[0] <= 32
+    return (len(mlp) == 3 and c + 3 <= 8 and mlp[0] <= 32
             and mlp[1] <= 32 and mlp[2] <= 128 and nsample in (16, 32))
 
 

@@ -339,44 +339,73 @@ __global__ __launch_bounds__(NS_THREADS) void ns_search_kernel(
     const f32x2 qx = {x1, x1}, qy = {y1, y1}, qz = {z1, z1};
     Top3K t = top3k_init();
     for (int tbase = 0; tbase < tiles_per_cloud; tbase += 64) {
-        // lane l: lower bound between the wave's query box and tile tbase + l
+        // lane l: box of tile tbase + l and the lower bound between it and the wave's query box
         const int nt = min(64, tiles_per_cloud - tbase);
         float lb = INFINITY;
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f, b4 = 0.f, b5 = 0.f;
         if (lane < nt) {
             const float *bx = tbc + (size_t)(tbase + lane) * 8;
-            const float g0 = fmaxf(fmaxf(bx[0] - qhi0, qlo0 - bx[3]), 0.f);
-            const float g1 = fmaxf(fmaxf(bx[1] - qhi1, qlo1 - bx[4]), 0.f);
-            const float g2 = fmaxf(fmaxf(bx[2] - qhi2, qlo2 - bx[5]), 0.f);
+            b0 = bx[0]; b1 = bx[1]; b2 = bx[2]; b3 = bx[3]; b4 = bx[4]; b5 = bx[5];
+            const float g0 = fmaxf(fmaxf(b0 - qhi0, qlo0 - b3), 0.f);
+            const float g1 = fmaxf(fmaxf(b1 - qhi1, qlo1 - b4), 0.f);
+            const float g2 = fmaxf(fmaxf(b2 - qhi2, qlo2 - b5), 0.f);
             lb = g0 * g0 + g1 * g1 + g2 * g2;                // same op order as sqd2(): unfused
             if (!(lb == lb)) lb = 0.f;                        // NaN box: never skip
         }
         int lbi = lane < nt ? f2i(lb) : 0x7fffffff;           // lb >= 0: int order = float order
-        for (;;) {
-            // nearest unvisited tile of the group (DPP reductions: no LDS round trips)
-            const int mn = -wave_max_i32(-lbi);
-            if (mn == 0x7fffffff) break;
-            const int worst = wave_max_i32(ok ? f2i(t.d3) : 0);   // distances >= +0: int order
-            if (mn > worst) break;                            // every remaining tile is farther
-            const unsigned long long who = __ballot(lbi == mn);
-            const int tl = __builtin_ctzll(who);
-            if (lane == tl) lbi = 0x7fffffff;
+        // Next tile worth a visit, nearest first, or -1.  The walk over this group of 64 tiles ends
+        // when the nearest unvisited tile is farther (box to box) than the worst third-best distance
+        // of the wave.  A tile inside that bound is still skipped when NO lane can use it: its own
+        // point-to-box bound (same unfused operations, monotone under rounding, so never above the
+        // computed distance of a pair it covers) exceeds its own third-best distance.  A wave whose
+        // 64 queries span a wide box (sparse far range: the waves that used to run 5x longer than
+        // the median and set the kernel's duration) thereby passes over most tiles in ~25
+        // instructions instead of scanning their 64 points.
+        auto next_tile = [&]() -> int {
+            for (;;) {
+                const int mn = -wave_max_i32(-lbi);
+                if (mn == 0x7fffffff) return -1;
+                const int worst = wave_max_i32(ok ? f2i(t.d3) : 0);   // distances >= +0: int order
+                if (mn > worst) return -1;                            // every remaining tile is farther
+                const unsigned long long who = __ballot(lbi == mn);
+                const int tl = __builtin_ctzll(who);
+                if (lane == tl) lbi = 0x7fffffff;
+                auto rl = [&](float v) { return i2f(__builtin_amdgcn_readlane(f2i(v), tl)); };   // bits, not value
+                const float t0 = rl(b0), t1 = rl(b1), t2 = rl(b2), t3 = rl(b3), t4 = rl(b4), t5 = rl(b5);
+                const float g0 = fmaxf(fmaxf(t0 - x1, x1 - t3), 0.f);
+                const float g1 = fmaxf(fmaxf(t1 - y1, y1 - t4), 0.f);
+                const float g2 = fmaxf(fmaxf(t2 - z1, z1 - t5), 0.f);
+                const float ll = g0 * g0 + g1 * g1 + g2 * g2;
+                // '<=': an equal distance with a smaller index must still get in; NaN: visit
+                if (__ballot(ok && !(ll > t.d3))) return tl;
+            }
+        };
+        // one tile ahead: the next tile's 1 KB is on its way from memory while this one is scanned
+        int tl = next_tile();
+        float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tl >= 0) nxt = kpc[(size_t)(tbase + tl) * 64 + lane];
+        while (tl >= 0) {
             __builtin_amdgcn_wave_barrier();                  // previous tile fully consumed
-            tp[lane] = kpc[(size_t)(tbase + tl) * 64 + lane];
+            tp[lane] = nxt;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // chosen with the distances known so far: they only shrink, so a tile rejected now stays
+            // rejected; one accepted now may turn out unnecessary (it is then scanned in vain)
+            tl = next_tile();
+            if (tl >= 0) nxt = kpc[(size_t)(tbase + tl) * 64 + lane];
 #pragma unroll 4
             for (int k = 0; k < 64; k += 4) {
-                const float4 a0 = tp[k], b0 = tp[k + 1], a1 = tp[k + 2], b1 = tp[k + 3];
-                const f32x2 da = sqd2(a0, b0, qx, qy, qz), db = sqd2(a1, b1, qx, qy, qz);
+                const float4 a0 = tp[k], b0_ = tp[k + 1], a1 = tp[k + 2], b1_ = tp[k + 3];
+                const f32x2 da = sqd2(a0, b0_, qx, qy, qz), db = sqd2(a1, b1_, qx, qy, qz);
                 const float mn4 = fminf(fminf(da[0], da[1]), fminf(db[0], db[1]));
                 // '<=': tiles are not visited in index order, an equal distance with a smaller
                 // index must still get in (the 64-bit key decides)
                 if (__builtin_amdgcn_ballot_w64(mn4 <= t.d3)) {
-                    if (__builtin_amdgcn_ballot_w64(da[0] <= t.d3)) top3k_insert(t, da[0], f2i(b0.z));
-                    if (__builtin_amdgcn_ballot_w64(da[1] <= t.d3)) top3k_insert(t, da[1], f2i(b0.w));
-                    if (__builtin_amdgcn_ballot_w64(db[0] <= t.d3)) top3k_insert(t, db[0], f2i(b1.z));
-                    if (__builtin_amdgcn_ballot_w64(db[1] <= t.d3)) top3k_insert(t, db[1], f2i(b1.w));
+                    if (__builtin_amdgcn_ballot_w64(da[0] <= t.d3)) top3k_insert(t, da[0], f2i(b0_.z));
+                    if (__builtin_amdgcn_ballot_w64(da[1] <= t.d3)) top3k_insert(t, da[1], f2i(b0_.w));
+                    if (__builtin_amdgcn_ballot_w64(db[0] <= t.d3)) top3k_insert(t, db[0], f2i(b1_.z));
+                    if (__builtin_amdgcn_ballot_w64(db[1] <= t.d3)) top3k_insert(t, db[1], f2i(b1_.w));
                 }
             }
         }
@@ -396,6 +425,53 @@ __global__ __launch_bounds__(NS_THREADS) void ns_search_kernel(
     const int rows = min(NS_THREADS, n - j0);
     const int cv = c / VEC;
     const float *pb = points2 + (size_t)bi * m * c;
+    if (cv <= NS_THREADS && NS_THREADS % cv == 0) {
+        // The thread's column group is the same for every row it handles (NS_THREADS is a multiple of
+        // c / VEC): the epilogue's per-column operands (t, the rows of u) are loaded ONCE, and the
+        // loop body is three gathered loads, the weighted sum, the narrow p1 product and one store
+        // -- the general form below re-reads 1 + 5 c1 values per element and made this phase the
+        // longer half of the fused kernel.
+        const int col = (tid % cv) * VEC;
+        const int rstep = NS_THREADS / cv;
+        float tv[VEC], uv[4][VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            tv[q] = epi >= 3 ? aff.t[col + q] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) uv[k][q] = (epi >= 3 && k < aff.c1) ? aff.u[(size_t)k * c + col + q] : 0.f;
+        }
+        for (int r = tid / cv; r < rows; r += rstep) {
+            const size_t qrow = (size_t)bi * n + s_q[r];
+            const vec_t a = *reinterpret_cast<const vec_t *>(pb + (size_t)s_i[r * 3] * c + col);
+            const vec_t bb = *reinterpret_cast<const vec_t *>(pb + (size_t)s_i[r * 3 + 1] * c + col);
+            const vec_t cc = *reinterpret_cast<const vec_t *>(pb + (size_t)s_i[r * 3 + 2] * c + col);
+            vec_t v = a * s_w[r * 3] + bb * s_w[r * 3 + 1] + cc * s_w[r * 3 + 2];   // unfused
+            vec_t *op = reinterpret_cast<vec_t *>(out + qrow * ldo + col);
+            if (epi >= 3) {                              // 3: affine + relu;  4: affine (EpiAffine)
+                // same operation order as epi_affine_add: x = t; x += p1[k] * u[k] (k ascending); v += x
+                float x[VEC];
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) x[q] = tv[q];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < aff.c1) {
+                        const float pv = aff.p1[qrow * aff.c1 + k];
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) x[q] += pv * uv[k][q];
+                    }
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) { v[q] += x[q]; if (epi == 3) v[q] = fmaxf(v[q], 0.f); }
+            } else if (epi) {                            // 1: out += v;  2: out = relu(out + v)
+                v = *op + v;
+                if (epi == 2) {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) v[q] = fmaxf(v[q], 0.f);
+                }
+            }
+            *op = v;
+        }
+        return;
+    }
     for (int e = tid; e < rows * cv; e += NS_THREADS) {
         const int r = e / cv;
         const int col = (e - r * cv) * VEC;

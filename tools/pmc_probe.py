@@ -51,6 +51,9 @@ def main():
     L2 = [(None,) + one(64), (torch.randn(64, 96, generator=g).mul_(0.1).to(dev),) + one(96),
           (torch.randn(96, 128, generator=g).mul_(0.1).to(dev),) + one(128)]
     L2[0] = (wx,) + one(64)
+    f128 = torch.randn(b, 4096, 128, generator=g).to(dev)
+    u4 = torch.randn(4, 128, generator=g).mul_(0.1).to(dev)
+    t128 = torch.zeros(128, device=dev)
     torch.cuda.synchronize()
     work = {
         "group_point_kernel<4>": b * 1024 * 32 * (4 + 8 * 96),
@@ -60,7 +63,7 @@ def main():
         "mlp_kernel<2, 2, 2, 2, false, false> rows65536 K608 N256": 4 * (b * 4096 * 608 + 608 * 256 + b * 4096 * 256),
         "mlp_kernel<4, 1, 1, 2, false, false, 32> rows4096 K512 N512": 4 * (b * 256 * 512 + 512 * 512 + b * 256 * 512),
         "mlp_kernel<2, 2, 2, 2, false, false> rows524288 K96 N128 pool32": 4 * (b * 1024 * 32 * 96 + 96 * 128 + b * 1024 * 128),
-        "ns_search_kernel<4, true> (culled three_nn + interpolate) n16384 m4096 C256": b * (12 * 16384 + 12 * 4096) + b * 16384 * 16 * 256,
+        "ns_search_kernel<4, true> (culled three_nn + interpolate + affine epilogue) n16384 m4096 C128 c1=4": b * (12 * 16384 + 12 * 4096) + b * 16384 * (16 * 128 + 16),
         "bq_culled_kernel<2> n16384 m4096 r0.1/0.5 ns16/32": b * (12 * 16384 + 12 * 4096 + 4 * 4096 * 48 + 8 * 4096),
         "sa_chain_kernel<4, 32, 32, 64> rows2097152": b * 4096 * 32 * (4 + 16) + 4 * b * 4096 * 64,
         "mlp_kernel<4, 1, 1, 2, true, false>": b * 1024 * 32 * (4 + 4 * 99) + 4 * b * 1024 * 32 * 64,
@@ -69,7 +72,7 @@ def main():
     for _ in range(REPS):
         ops.group_point(f1, idx2)
         ops.three_interpolate(f256, i3, w)
-        ops.three_nn_interpolate(xyz, new1, f256)
+        ops.three_nn_interpolate_affine(xyz, new1, f128, pc, u4, t128)     # last RPN FP level as the stack runs it
         ops.mlp_layer(x260, W260, *one(128))
         ops.mlp_layer(x608, W608, *one(256))
         ops.mlp_layer(x96, W96, *one(128), pool=32)

@@ -431,7 +431,7 @@ PMC_KEYS = {
     ("mlp_layer", "rows4096 K512 N512 pool1"): "mlp_kernel<4, 1, 1, 2, false, false, 32, false> grid_threads=65536",
     ("three_interpolate", None): "three_interpolate_kernel<4>",
     ("group_point", None): "group_point_kernel<4>",
-    ("three_nn_interpolate", None): "three_nn_interpolate_kernel<4>",
+    ("three_nn_interpolate", None): "ns_search_kernel<4, true>",
 }
 HBM_KERNELS = ("group_point", "three_interpolate", "three_nn_interpolate", "gather_point", "sa_group_add_layer")
 

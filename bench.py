@@ -478,6 +478,19 @@ def main():
         ctypes.CDLL(os.path.join(ROOT, "tools", "libsegv_bt.so")).segv_bt_install()
 
     PU.SA_DEDUP = not args.no_dedup
+    # Hardware queues.  The schedule keeps four streams busy (two step streams + the FPS branch of each
+    # unit's graph) and its throughput depends on how HIP deals its hardware queues to the process's
+    # live streams: with the default of 4 queues a run WITHOUT a process group is at full speed, but
+    # one more live stream -- RCCL's, or any idle stream created earlier -- costs 24 % (measured:
+    # 10.8k -> 8.3k scenes/s); with 8 queues the run WITH a one-rank RCCL group is back at 10.9k (and the
+    # run without a group drops to 7.6k).  DESIGN.md 5 has the table.  So: 8 queues when a process group
+    # will be formed, the default otherwise (PRCNN_HW_QUEUES overrides); the variable is read when HIP
+    # initialises (first HIP call, below).
+    grouped = int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("PRCNN_DIST_FORCE") == "1"
+    if os.environ.get("PRCNN_HW_QUEUES"):                       # explicit choice for this bench
+        os.environ["GPU_MAX_HW_QUEUES"] = os.environ["PRCNN_HW_QUEUES"]
+    elif grouped and os.environ.get("GPU_MAX_HW_QUEUES", "4") == "4":   # unset, or exported at HIP's own default
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
     rank, world, local = pdist.init_from_env("cuda")
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
@@ -500,6 +513,17 @@ def main():
                                      pcs, prop, store, precision)
         return SimpleSchedule(device, nstreams, not args.no_graph, args.geo_stream, pcs, prop, store, precision)
 
+    # probe: streams created (and used once) before the schedule's, to shift the stream -> hardware queue
+    # assignment of the streams that matter (HIP hands its 4 hardware queues out in creation order)
+    pad_streams = [torch.cuda.Stream(device=device) for _ in range(int(os.environ.get("PRCNN_BENCH_PAD_STREAMS", "0")))]
+    for ps in pad_streams:
+        with torch.cuda.stream(ps):
+            torch.zeros(1, device=device)
+    torch.cuda.synchronize()
+    if os.environ.get("PRCNN_BENCH_PAD_DROP") == "1":
+        del pad_streams, ps
+        import gc
+        gc.collect()
     sched = make_schedule()
     elapsed, t_issue, gathered = timed_region(sched, args.steps, args.warmup, ring, device, world)
 
@@ -632,7 +656,7 @@ def main():
                        "hip_graph": hip_graph, "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3),
                        "geometry_streams": bool(args.geo_stream), "fps_one_step_ahead": bool(pipelined),
                        "duplicate_free_groups": bool(PU.SA_DEDUP), "ball_fill": ball_fill(pcs),
-                       "batches_per_replay": group, "eager_remainder_steps": (args.steps % group) if pipelined else 0,
+                       "batches_per_replay": group, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "eager_remainder_steps": (args.steps % group) if pipelined else 0,
                        "replay_equals_eager": replay_ok,
                        "kernel_timing": "HIP events around every launch in an eager, single-stream instrumented "
                                         "pass of the same steps after the timed region",

@@ -8,22 +8,24 @@ Workload (BASELINE.json configs[2], the config the metric "SA/FP-stack scenes/se
 (16k pts)" is quoted on): the PointRCNN RPN SA+FP stack on a batch of 16 synthetic
 KITTI-shaped scenes x 16384 points per GPU, fused group->shared-MLP->max-pool on the
 matrix cores, followed by the rotated BEV NMS of each scene's 2048 proposals (top 100,
-IoU 0.8: the reference's val/test setting) and -- for N>1 -- ONE RCCL all-gather of all
-per-scene detection records produced in the timed region, issued at its closing fence.  One "step" = one such batch per rank (weak scaling: every
-rank processes its own 16 scenes per step).  Inputs are resident in HBM before the timed
-region.  Steps are issued as HIP-graph replays of `--fps-group` (default 4) batches each,
-alternating over two streams (a remainder of K mod 4 steps runs as single-batch replays, so
-exactly K steps are timed).  Inside a replay the strictly serial farthest-point-sampling
-chain runs ONCE over the clouds of that stream's NEXT four batches (64 workgroups, 6.3 ms
-whatever the number of clouds) beside the full-chip feature phases of the current four
-(software pipelining: every batch still gets one complete FPS pass and one complete feature
-phase, see pipelined_step; --no-pipeline samples inside the batch's own step, --fps-group 1
-pipelines batch by batch).
+IoU 0.8: the reference's val/test setting) and ONE all-gather (RCCL for N>1) of all
+per-scene detection records produced in the timed region, issued at its closing fence.
+One "step" = one such batch per rank (weak scaling).  Inputs are resident in HBM before
+the timed region; nothing is allocated inside it.
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant roofline-bound
-kernel, durations measured with HIP events inside the timed region), `kernels` (every
-kernel family), `fps` (the latency-bound sampler: us/iteration), `nms` (ms @ 9000 boxes),
-`cpu_baseline` (the CPU oracle = reference CPU path, 1 core, bounded sample).
+Schedule (PipelinedSchedule / Unit): one HIP graph per step stream holding the feature
+phases of `group` batches and, on a forked branch, ONE farthest-point-sampling chain
+over the clouds of the NEXT `group` batches (software pipelining: every batch still
+gets one complete FPS pass and one complete feature phase); K mod group remainder steps
+run eagerly, so exactly K steps are timed for any K.  After the timed region a replay's
+features and records are compared bit for bit with an eager, un-pipelined step.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant roofline-bound launch;
+durations from HIP events in an eager single-stream pass, HBM traffic from the committed
+rocprofv3 PMC passes), `kernels` (every op family), `fps` (the latency-bound sampler: us per
+iteration + SQ counters), `nms` (ms @ 9000 boxes), `value_no_dedup` (the same timed region
+with every padded ball slot evaluated), `single_scene_latency_ms`, `frustum`, `fps_dense`,
+`cpu_baseline` (the CPU oracle = reference CPU path: 1 core, and farmed over 16 processes).
 """
 import argparse
 import json

@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpointrcnn_hip.so")
+LIB_PATH = os.environ.get("PRCNN_LIB") or os.path.join(_HERE, "libpointrcnn_hip.so")    # PRCNN_LIB: A/B builds of the same ABI
 
 _c = ctypes
 _vp, _i, _f, _d, _i64, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_double, _c.c_int64, _c.c_size_t

@@ -474,6 +474,10 @@ static int launch_mlp(const MlpArgs &a, hipStream_t st)
     // workgroup has its SIMDs to itself and the two barriers per chunk are exposed: rows4096 K512
     // N512 31.5 -> 28.9 us, rows1024 K1024 N512 47 -> 32 us with 32-deep chunks
     if (!BF16 && a.cin >= 512 && rb * ((a.cout + bn - 1) / bn) <= 256) kb = 32;
+    // and on the 128-wide tile from K = 256 on (round-2 re-measurement, 4 waves/SIMD build: rows65536 K256
+    // N256 99.0 -> 92.3 us, rows16384 K512 N512 86.3 -> 83.6 us, rows65536 K608 N256 191 -> 182 us; K128
+    // unchanged).  Same accumulation order either way (sub-chunks of 16).
+    if (!BF16 && bn == 128 && a.cin >= 256) kb = 32;
     if (const char *f = getenv("PRCNN_MLP_KB")) kb = atoi(f);   // tuning aid (16 / 32)
     if (a.rows_dev) {
         // compacted rows: 64-column tiles, 32-deep chunks (few row blocks exist: more workgroups

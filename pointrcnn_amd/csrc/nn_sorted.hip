@@ -20,7 +20,10 @@
 
 namespace prcnn {
 
-constexpr int NS_THREADS = 256;
+#ifndef NS_NW
+#define NS_NW 4
+#endif
+constexpr int NS_THREADS = 64 * NS_NW;      // search kernel: NS_NW waves share one block of 64 queries
 constexpr int NS_KEY_BITS = 15;           // grid cells per cloud = 32768 (128 KB LDS histogram)
 constexpr int NS_CELLS = 1 << NS_KEY_BITS;
 
@@ -305,6 +308,19 @@ __device__ __forceinline__ void fp_weights3s(float d0, float d1, float d2, float
 }
 
 // ---- 4. search (+ optional fused interpolation) --------------------------------------------
+// A workgroup owns NS_QPB = 64 consecutive sorted queries; its FOUR waves all hold the same 64 queries
+// (one per lane) and share the tiles among them: wave w visits tiles t with t % 4 == w, nearest
+// first, keeping its own top three.  The waves publish their current third-best distance per query
+// in LDS; the minimum over the four is an upper bound of the final third-best (each wave's list is a
+// subset of all candidates), so every wave prunes tiles and screens candidates with it.  The final
+// three are the three smallest (distance, index) keys of the union of the four lists (merge below).
+// Why: with one wave per 64 queries, the cost of a wave spreads 4-5x around its mean (6.7 tiles and 88
+// insertions on average, 25 and 430 at worst, RPN level 1) and all waves are resident at once, so the
+// kernel lasted as long as its slowest wave: 98 us at an average wave residency of 28 us.  Four
+// waves per block cut the longest dependent chain by four and give the dispatcher four rounds of
+// workgroups to balance.
+constexpr int NS_QPB = 64;
+
 template <int VEC, bool INTERP>
 __global__ __launch_bounds__(NS_THREADS) void ns_search_kernel(
     int n, int m, int c, int tiles_per_cloud, const float *__restrict__ xyz1,
@@ -314,36 +330,40 @@ __global__ __launch_bounds__(NS_THREADS) void ns_search_kernel(
     EpiAffine aff)
 {
     typedef float vec_t __attribute__((ext_vector_type(VEC)));
-    // Waves are independent: each stages the tile it visits in its own 1 KB of LDS (no
-    // workgroup barrier anywhere in the search, so a wave with many tiles to visit never
-    // holds up its neighbours).
-    __shared__ float4 wtile[NS_THREADS / 64][64];
-    __shared__ int s_q[NS_THREADS];
-    __shared__ int s_i[NS_THREADS * 3];
-    __shared__ float s_w[NS_THREADS * 3];
+    __shared__ float s_d3[NS_THREADS / 64][NS_QPB];
+    __shared__ unsigned long long s_key[NS_THREADS / 64][3][NS_QPB];
+    __shared__ int s_q[NS_QPB];
+    __shared__ int s_i[NS_QPB * 3];
+    __shared__ float s_w[NS_QPB * 3];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bi = blockIdx.y;
-    const int j0 = blockIdx.x * NS_THREADS;
-    const int js = j0 + tid;                       // position in sorted order
+    const int j0 = blockIdx.x * NS_QPB;
+    const int js = j0 + lane;                      // position in sorted order
     const bool ok = js < n;
     const int qi = qsorted[(size_t)bi * n + (ok ? js : n - 1)];
     const float *q = xyz1 + ((size_t)bi * n + qi) * 3;
     const float x1 = q[0], y1 = q[1], z1 = q[2];
-    // the wave's query box (lanes past n repeat the last query: no effect on the box)
+    // the block's query box (lanes past n repeat the last query: no effect on the box)
     const float qlo0 = wave_minf(x1), qlo1 = wave_minf(y1), qlo2 = wave_minf(z1);
     const float qhi0 = wave_maxf(x1), qhi1 = wave_maxf(y1), qhi2 = wave_maxf(z1);
     const float4 *kpc = kp + (size_t)bi * tiles_per_cloud * 64;
     const float *tbc = tb + (size_t)bi * tiles_per_cloud * 8;
-    float4 *tp = wtile[wave];
     const f32x2 qx = {x1, x1}, qy = {y1, y1}, qz = {z1, z1};
     Top3K t = top3k_init();
+    // published third-best distances: read without ordering (any value ever published is a valid
+    // bound; they only shrink)
+    volatile float *vd3 = &s_d3[0][0];
+    vd3[wave * NS_QPB + lane] = INFINITY;
+    __syncthreads();
+    float sd = INFINITY;                           // screening bound: min over the four waves
     for (int tbase = 0; tbase < tiles_per_cloud; tbase += 64) {
-        // lane l: box of tile tbase + l and the lower bound between it and the wave's query box
+        // lane l: box of tile tbase + l and the lower bound between it and the block's query box
         const int nt = min(64, tiles_per_cloud - tbase);
+        const bool mine = lane < nt && (lane % NS_NW) == wave;    // tbase % NS_NW == 0
         float lb = INFINITY;
         float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f, b4 = 0.f, b5 = 0.f;
-        if (lane < nt) {
+        if (mine) {
             const float *bx = tbc + (size_t)(tbase + lane) * 8;
             b0 = bx[0]; b1 = bx[1]; b2 = bx[2]; b3 = bx[3]; b4 = bx[4]; b5 = bx[5];
             const float g0 = fmaxf(fmaxf(b0 - qhi0, qlo0 - b3), 0.f);
@@ -352,20 +372,19 @@ __global__ __launch_bounds__(NS_THREADS) void ns_search_kernel(
             lb = g0 * g0 + g1 * g1 + g2 * g2;                // same op order as sqd2(): unfused
             if (!(lb == lb)) lb = 0.f;                        // NaN box: never skip
         }
-        int lbi = lane < nt ? f2i(lb) : 0x7fffffff;           // lb >= 0: int order = float order
-        // Next tile worth a visit, nearest first, or -1.  The walk over this group of 64 tiles ends
-        // when the nearest unvisited tile is farther (box to box) than the worst third-best distance
-        // of the wave.  A tile inside that bound is still skipped when NO lane can use it: its own
+        int lbi = mine ? f2i(lb) : 0x7fffffff;                // lb >= 0: int order = float order
+        // Next tile worth a visit, nearest first, or -1.  The walk over this group of tiles ends
+        // when the nearest unvisited tile is farther (box to box) than the worst bound of the 64
+        // queries.  A tile inside that bound is still skipped when NO lane can use it: its own
         // point-to-box bound (same unfused operations, monotone under rounding, so never above the
-        // computed distance of a pair it covers) exceeds its own third-best distance.  A wave whose
-        // 64 queries span a wide box (sparse far range: the waves that used to run 5x longer than
-        // the median and set the kernel's duration) thereby passes over most tiles in ~25
-        // instructions instead of scanning their 64 points.
+        // computed distance of a pair it covers) exceeds its own bound.
         auto next_tile = [&]() -> int {
+#pragma unroll
+            for (int w = 0; w < NS_NW; ++w) sd = fminf(sd, vd3[w * NS_QPB + lane]);
+            const int worst = wave_max_i32(ok ? f2i(sd) : 0);         // distances >= +0: int order
             for (;;) {
                 const int mn = -wave_max_i32(-lbi);
                 if (mn == 0x7fffffff) return -1;
-                const int worst = wave_max_i32(ok ? f2i(t.d3) : 0);   // distances >= +0: int order
                 if (mn > worst) return -1;                            // every remaining tile is farther
                 const unsigned long long who = __ballot(lbi == mn);
                 const int tl = __builtin_ctzll(who);
@@ -377,52 +396,60 @@ __global__ __launch_bounds__(NS_THREADS) void ns_search_kernel(
                 const float g2 = fmaxf(fmaxf(t2 - z1, z1 - t5), 0.f);
                 const float ll = g0 * g0 + g1 * g1 + g2 * g2;
                 // '<=': an equal distance with a smaller index must still get in; NaN: visit
-                if (__ballot(ok && !(ll > t.d3))) return tl;
+                if (__ballot(ok && !(ll > sd))) return tl;
             }
         };
-        // one tile ahead: the next tile's 1 KB is on its way from memory while this one is scanned
-        int tl = next_tile();
-        float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tl >= 0) nxt = kpc[(size_t)(tbase + tl) * 64 + lane];
-        while (tl >= 0) {
-            __builtin_amdgcn_wave_barrier();                  // previous tile fully consumed
-            tp[lane] = nxt;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // chosen with the distances known so far: they only shrink, so a tile rejected now stays
-            // rejected; one accepted now may turn out unnecessary (it is then scanned in vain)
-            tl = next_tile();
-            if (tl >= 0) nxt = kpc[(size_t)(tbase + tl) * 64 + lane];
+        // The tile's 64 points are the same for every lane: they are read through the scalar cache
+        // (wave-uniform address into memory this kernel never writes) and enter the packed operations
+        // as scalar operands -- no LDS staging, no LDS bandwidth (four waves per SIMD reading 64 B per
+        // lane per step through the CU's one LDS port was the kernel's bound).
+        for (int tl = next_tile(); tl >= 0; tl = next_tile()) {
+            const float4 *kt = kpc + (size_t)(tbase + tl) * 64;
 #pragma unroll 4
             for (int k = 0; k < 64; k += 4) {
-                const float4 a0 = tp[k], b0_ = tp[k + 1], a1 = tp[k + 2], b1_ = tp[k + 3];
+                const float4 a0 = kt[k], b0_ = kt[k + 1], a1 = kt[k + 2], b1_ = kt[k + 3];
                 const f32x2 da = sqd2(a0, b0_, qx, qy, qz), db = sqd2(a1, b1_, qx, qy, qz);
                 const float mn4 = fminf(fminf(da[0], da[1]), fminf(db[0], db[1]));
                 // '<=': tiles are not visited in index order, an equal distance with a smaller
                 // index must still get in (the 64-bit key decides)
-                if (__builtin_amdgcn_ballot_w64(mn4 <= t.d3)) {
-                    if (__builtin_amdgcn_ballot_w64(da[0] <= t.d3)) top3k_insert(t, da[0], f2i(b0_.z));
-                    if (__builtin_amdgcn_ballot_w64(da[1] <= t.d3)) top3k_insert(t, da[1], f2i(b0_.w));
-                    if (__builtin_amdgcn_ballot_w64(db[0] <= t.d3)) top3k_insert(t, db[0], f2i(b1_.z));
-                    if (__builtin_amdgcn_ballot_w64(db[1] <= t.d3)) top3k_insert(t, db[1], f2i(b1_.w));
+                if (__builtin_amdgcn_ballot_w64(mn4 <= sd)) {
+                    if (__builtin_amdgcn_ballot_w64(da[0] <= sd)) { top3k_insert(t, da[0], f2i(b0_.z)); sd = fminf(sd, t.d3); }
+                    if (__builtin_amdgcn_ballot_w64(da[1] <= sd)) { top3k_insert(t, da[1], f2i(b0_.w)); sd = fminf(sd, t.d3); }
+                    if (__builtin_amdgcn_ballot_w64(db[0] <= sd)) { top3k_insert(t, db[0], f2i(b1_.z)); sd = fminf(sd, t.d3); }
+                    if (__builtin_amdgcn_ballot_w64(db[1] <= sd)) { top3k_insert(t, db[1], f2i(b1_.w)); sd = fminf(sd, t.d3); }
                 }
             }
+            vd3[wave * NS_QPB + lane] = t.d3;
         }
     }
-    if (ok) {
-        const size_t o = ((size_t)bi * n + qi) * 3;
-        if (dist) { dist[o] = top3k_dist(t.k1); dist[o + 1] = top3k_dist(t.k2); dist[o + 2] = top3k_dist(t.k3); }
-        if (idx) { idx[o] = top3k_index(t.k1); idx[o + 1] = top3k_index(t.k2); idx[o + 2] = top3k_index(t.k3); }
-    }
-    if (!INTERP) return;
-    float w0, w1, w2;
-    fp_weights3s(top3k_dist(t.k1), top3k_dist(t.k2), top3k_dist(t.k3), w0, w1, w2);
-    s_q[tid] = qi;
-    s_i[tid * 3] = top3k_index(t.k1); s_i[tid * 3 + 1] = top3k_index(t.k2); s_i[tid * 3 + 2] = top3k_index(t.k3);
-    s_w[tid * 3] = w0; s_w[tid * 3 + 1] = w1; s_w[tid * 3 + 2] = w2;
+    // merge: the three smallest keys of the four lists (a candidate some wave screened out lies above
+    // the final third-best; the final three each sit in the list of the wave that met them)
+    s_key[wave][0][lane] = t.k1; s_key[wave][1][lane] = t.k2; s_key[wave][2][lane] = t.k3;
     __syncthreads();
-    const int rows = min(NS_THREADS, n - j0);
+    if (wave != 0) {
+        if (!INTERP) return;
+    } else {
+#pragma unroll
+        for (int w = 1; w < NS_THREADS / 64; ++w)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const unsigned long long k = s_key[w][r][lane];
+                top3k_insert(t, top3k_dist(k), top3k_index(k));
+            }
+        if (ok) {
+            const size_t o = ((size_t)bi * n + qi) * 3;
+            if (dist) { dist[o] = top3k_dist(t.k1); dist[o + 1] = top3k_dist(t.k2); dist[o + 2] = top3k_dist(t.k3); }
+            if (idx) { idx[o] = top3k_index(t.k1); idx[o + 1] = top3k_index(t.k2); idx[o + 2] = top3k_index(t.k3); }
+        }
+        if (!INTERP) return;
+        float w0, w1, w2;
+        fp_weights3s(top3k_dist(t.k1), top3k_dist(t.k2), top3k_dist(t.k3), w0, w1, w2);
+        s_q[lane] = qi;
+        s_i[lane * 3] = top3k_index(t.k1); s_i[lane * 3 + 1] = top3k_index(t.k2); s_i[lane * 3 + 2] = top3k_index(t.k3);
+        s_w[lane * 3] = w0; s_w[lane * 3 + 1] = w1; s_w[lane * 3 + 2] = w2;
+    }
+    __syncthreads();
+    const int rows = min(NS_QPB, n - j0);
     const int cv = c / VEC;
     const float *pb = points2 + (size_t)bi * m * c;
     if (cv <= NS_THREADS && NS_THREADS % cv == 0) {
@@ -541,7 +568,7 @@ static int ns_run(int b, int n, int m, int c, const float *xyz1, const float *xy
     const long long total_tiles = (long long)b * tiles;
     hipLaunchKernelGGL(ns_tile_kernel<true>, dim3((unsigned)((total_tiles + 3) / 4)), dim3(256), 0, st, m, tiles,
                        total_tiles, xyz2, w.list_k, w.kp, w.tb);
-    dim3 grid((n + NS_THREADS - 1) / NS_THREADS, b);
+    dim3 grid((n + NS_QPB - 1) / NS_QPB, b);
     if (!points2) {
         hipLaunchKernelGGL((ns_search_kernel<1, false>), grid, dim3(NS_THREADS), 0, st, n, m, 0, tiles, xyz1,
                            w.list_q, w.kp, w.tb, nullptr, nullptr, 0ll, dist, idx, 0, aff);
@@ -640,10 +667,15 @@ __global__ __launch_bounds__(256) void bq_culled_kernel(int n, int m, int tiles,
             cand = !(lb >= thrmax);                          // NaN bound: visit
         }
         unsigned long long todo = __ballot(cand);
+        // one tile ahead: the next candidate tile's points are on their way while this one is tested
+        // (the walk is a chain of dependent memory round trips otherwise: a wave does ~40 VALU
+        // instructions per tile)
+        float4 pn = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (todo) pn = ppc[(size_t)(tbase + __builtin_ctzll(todo)) * 64 + lane];
         while (todo) {
-            const int tl = __builtin_ctzll(todo);
             todo &= todo - 1;
-            const float4 p = ppc[(size_t)(tbase + tl) * 64 + lane];   // NaN padding never hits
+            const float4 p = pn;                                      // NaN padding never hits
+            if (todo) pn = ppc[(size_t)(tbase + __builtin_ctzll(todo)) * 64 + lane];
             const int k = f2i(p.w);
             const f32x2 px = {p.x, p.x}, py = {p.y, p.y}, pz = {p.z, p.z};
 #pragma unroll

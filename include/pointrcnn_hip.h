@@ -361,6 +361,36 @@ int prcnn_query_ball_point_msg_sorted(int b, int n, int m, int nscales, const fl
                                       int *const *host_pts_cnt, void *workspace,
                                       size_t workspace_bytes, prcnn_stream_t stream);
 
+/* ---- one grid order for several searches over the same two point sets (additive) ---------------
+ * The culled searches above start by ordering both point sets along the cells of a grid over their
+ * JOINT bounding box.  The order depends on the two sets only, not on which is the query side, so
+ * searches over the same pair -- in the RPN stack the level-1 ball query (points = the cloud,
+ * centroids = level-1 new_xyz, models/pointnet_util.py:141-160 via rpn.py:166) and the last FP
+ * level's three_nn (unknown = the cloud, known = level-1 new_xyz, pointnet_util.py:210 via
+ * rpn.py:192) -- can share it: prcnn_grid_order once, then the *_ordered entry points, which skip
+ * their own ordering pass.  order1 (b,n) / order2 (b,m): point indices of xyz1 / xyz2 in grid
+ * order (the order inside a cell is unspecified; no result depends on it).  The *_ordered entry
+ * points take (order1, order2) for THEIR (xyz1, xyz2): swap the two when the roles are swapped.
+ * Both NULL = same as the entry point without the suffix.  Results are bit-identical either way. */
+int prcnn_grid_order(int b, int n, int m, const float *xyz1, const float *xyz2, int *order1,
+                     int *order2, prcnn_stream_t stream);
+int prcnn_three_nn_ordered(int b, int n, int m, const float *xyz1, const float *xyz2,
+                           const int *order1, const int *order2, float *dist, int *idx,
+                           void *workspace, size_t workspace_bytes, prcnn_stream_t stream);
+int prcnn_three_nn_interpolate_affine_ordered(int b, int n, int m, int c, const float *xyz1,
+                                              const float *xyz2, const int *order1,
+                                              const int *order2, const float *points2,
+                                              const float *p1, int c1, const float *u,
+                                              const float *t, float *out, int64_t ldo, int relu,
+                                              void *workspace, size_t workspace_bytes,
+                                              prcnn_stream_t stream);
+int prcnn_query_ball_point_msg_ordered(int b, int n, int m, int nscales, const float *host_radii,
+                                       const int *host_nsamples, const float *xyz1,
+                                       const float *xyz2, const int *order1, const int *order2,
+                                       int *const *host_idx, int *const *host_pts_cnt,
+                                       void *workspace, size_t workspace_bytes,
+                                       prcnn_stream_t stream);
+
 /* ---- backward ops ------------------------------------------------
  * All three are ordered segmented reductions: every output element is summed in exactly
  * the order of the reference's serial CPU loops, so results are deterministic and equal

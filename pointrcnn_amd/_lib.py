@@ -67,6 +67,11 @@ SIGNATURES = {
     "prcnn_three_interpolate_affine": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i64, _i, _vp]),
     "prcnn_query_ball_point_sorted_workspace_bytes": (_sz, [_i, _i, _i]),
     "prcnn_query_ball_point_msg_sorted": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "prcnn_grid_order": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "prcnn_three_nn_ordered": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "prcnn_three_nn_interpolate_affine_ordered": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp,
+                                                       _i64, _i, _vp, _sz, _vp]),
+    "prcnn_query_ball_point_msg_ordered": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "prcnn_selection_sort": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "prcnn_knn_point": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "prcnn_rpn_decode_proposals": (_i, [_i, _i, _i, _i, _i, _f, _f, _vp] + [_vp] * 9 + [_vp]),

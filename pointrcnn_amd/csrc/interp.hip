@@ -357,7 +357,8 @@ extern "C" int prcnn_three_nn_interpolate(int b, int n, int m, int c, const floa
 // declared in nn_sorted.hip
 int prcnn_ns_fused(int b, int n, int m, int c, const float *xyz1, const float *xyz2, const float *points2,
                    float *out, int64_t ldo, float *dist, int *idx, int epi, const prcnn::EpiAffine *aff,
-                   void *ws, size_t ws_bytes, prcnn_stream_t stream);
+                   void *ws, size_t ws_bytes, prcnn_stream_t stream, const int *order1 = nullptr,
+                   const int *order2 = nullptr);
 
 extern "C" int prcnn_three_nn_interpolate_add(int b, int n, int m, int c, const float *xyz1,
                                               const float *xyz2, const float *points2, float *out,
@@ -371,18 +372,30 @@ extern "C" int prcnn_three_nn_interpolate_add(int b, int n, int m, int c, const 
     return launch_fused_nn(b, n, m, c, xyz1, xyz2, points2, out, ldo, nullptr, nullptr, epi, stream);
 }
 
+extern "C" int prcnn_three_nn_interpolate_affine_ordered(int b, int n, int m, int c, const float *xyz1,
+                                                         const float *xyz2, const int *order1, const int *order2,
+                                                         const float *points2, const float *p1, int c1,
+                                                         const float *u, const float *t, float *out, int64_t ldo,
+                                                         int relu, void *workspace, size_t workspace_bytes,
+                                                         prcnn_stream_t stream)
+{
+    if (c1 < 0 || c1 > 4) return PRCNN_UNSUPPORTED;
+    if (!t || (c1 > 0 && (!p1 || !u))) return PRCNN_BAD_SHAPE;
+    if ((order1 == nullptr) != (order2 == nullptr) || (order1 && !workspace)) return PRCNN_BAD_ARG;
+    prcnn::EpiAffine aff = {p1, u, t, c1};
+    const int epi = relu ? 3 : 4;
+    if (workspace)
+        return prcnn_ns_fused(b, n, m, c, xyz1, xyz2, points2, out, ldo, nullptr, nullptr, epi, &aff, workspace,
+                              workspace_bytes, stream, order1, order2);
+    return launch_fused_nn(b, n, m, c, xyz1, xyz2, points2, out, ldo, nullptr, nullptr, epi, stream, aff);
+}
+
 extern "C" int prcnn_three_nn_interpolate_affine(int b, int n, int m, int c, const float *xyz1,
                                                  const float *xyz2, const float *points2, const float *p1,
                                                  int c1, const float *u, const float *t, float *out,
                                                  int64_t ldo, int relu, void *workspace,
                                                  size_t workspace_bytes, prcnn_stream_t stream)
 {
-    if (c1 < 0 || c1 > 4) return PRCNN_UNSUPPORTED;
-    if (!t || (c1 > 0 && (!p1 || !u))) return PRCNN_BAD_SHAPE;
-    prcnn::EpiAffine aff = {p1, u, t, c1};
-    const int epi = relu ? 3 : 4;
-    if (workspace)
-        return prcnn_ns_fused(b, n, m, c, xyz1, xyz2, points2, out, ldo, nullptr, nullptr, epi, &aff, workspace,
-                              workspace_bytes, stream);
-    return launch_fused_nn(b, n, m, c, xyz1, xyz2, points2, out, ldo, nullptr, nullptr, epi, stream, aff);
+    return prcnn_three_nn_interpolate_affine_ordered(b, n, m, c, xyz1, xyz2, nullptr, nullptr, points2, p1, c1, u, t,
+                                                     out, ldo, relu, workspace, workspace_bytes, stream);
 }

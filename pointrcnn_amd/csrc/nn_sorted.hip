@@ -556,15 +556,19 @@ static NsWs ns_carve(void *ws, long long b, long long n, long long m)
     return w;
 }
 
+// order_q / order_k: grid orders of xyz1 / xyz2 computed beforehand (prcnn_grid_order on the same two sets,
+// in either role): the sort launch is skipped
 static int ns_run(int b, int n, int m, int c, const float *xyz1, const float *xyz2, const float *points2,
                   float *out, long long ldo, float *dist, int *idx, void *ws, size_t ws_bytes, hipStream_t st,
-                  int epi = 0, EpiAffine aff = EpiAffine{})
+                  int epi = 0, EpiAffine aff = EpiAffine{}, const int *order_q = nullptr, const int *order_k = nullptr)
 {
     NsWs w = ns_carve(ws, b, n, m);
     if (!ws || ws_bytes < w.bytes) return PRCNN_WORKSPACE;
     if (((uintptr_t)ws & 255) != 0) return PRCNN_BAD_ARG;
+    if ((order_q == nullptr) != (order_k == nullptr)) return PRCNN_BAD_ARG;
     const int tiles = (m + 63) / 64;
-    launch_ns_sort(b, n, m, xyz1, xyz2, w.list_q, w.list_k, st);
+    if (order_q) { w.list_q = const_cast<int *>(order_q); w.list_k = const_cast<int *>(order_k); }
+    else launch_ns_sort(b, n, m, xyz1, xyz2, w.list_q, w.list_k, st);
     const long long total_tiles = (long long)b * tiles;
     hipLaunchKernelGGL(ns_tile_kernel<true>, dim3((unsigned)((total_tiles + 3) / 4)), dim3(256), 0, st, m, tiles,
                        total_tiles, xyz2, w.list_k, w.kp, w.tb);
@@ -723,14 +727,17 @@ __global__ __launch_bounds__(256) void bq_culled_kernel(int n, int m, int tiles,
 }
 
 static int bq_run(int b, int n, int m, int nscales, const BallScales &sc, const float *xyz1, const float *xyz2,
-                  void *ws, size_t ws_bytes, hipStream_t st)
+                  void *ws, size_t ws_bytes, hipStream_t st, const int *order_points = nullptr,
+                  const int *order_centroids = nullptr)
 {
     // queries = centroids (m), known = points (n)
     NsWs w = ns_carve(ws, b, m, n);
     if (!ws || ws_bytes < w.bytes) return PRCNN_WORKSPACE;
     if (((uintptr_t)ws & 255) != 0) return PRCNN_BAD_ARG;
+    if ((order_points == nullptr) != (order_centroids == nullptr)) return PRCNN_BAD_ARG;
     const int tiles = (n + 63) / 64;
-    launch_ns_sort(b, m, n, xyz2, xyz1, w.list_q, w.list_k, st);
+    if (order_points) { w.list_q = const_cast<int *>(order_centroids); w.list_k = const_cast<int *>(order_points); }
+    else launch_ns_sort(b, m, n, xyz2, xyz1, w.list_q, w.list_k, st);
     const long long total_tiles = (long long)b * tiles;
     hipLaunchKernelGGL(ns_tile_kernel<false>, dim3((unsigned)((total_tiles + 3) / 4)), dim3(256), 0, st, n, tiles,
                        total_tiles, xyz1, w.list_k, w.kp, w.tb);
@@ -765,6 +772,30 @@ extern "C" int prcnn_three_nn_sorted(int b, int n, int m, const float *xyz1, con
                          to_stream(stream));
 }
 
+extern "C" int prcnn_grid_order(int b, int n, int m, const float *xyz1, const float *xyz2, int *order1, int *order2,
+                                prcnn_stream_t stream)
+{
+    if (b < 0 || n <= 0 || m <= 0) return PRCNN_BAD_SHAPE;
+    if (b == 0) return PRCNN_OK;
+    if (!xyz1 || !xyz2 || !order1 || !order2) return PRCNN_BAD_SHAPE;
+    if (b > 65535) return PRCNN_UNSUPPORTED;
+    prcnn::launch_ns_sort(b, n, m, xyz1, xyz2, order1, order2, to_stream(stream));
+    PRCNN_LAUNCH_CHECK();
+    return PRCNN_OK;
+}
+
+extern "C" int prcnn_three_nn_ordered(int b, int n, int m, const float *xyz1, const float *xyz2, const int *order1,
+                                      const int *order2, float *dist, int *idx, void *workspace,
+                                      size_t workspace_bytes, prcnn_stream_t stream)
+{
+    if (b < 0 || n < 0 || m <= 0) return PRCNN_BAD_SHAPE;
+    if (b == 0 || n == 0) return PRCNN_OK;
+    if (!xyz1 || !xyz2 || !dist || !idx) return PRCNN_BAD_SHAPE;
+    if (b > 65535) return PRCNN_UNSUPPORTED;
+    return prcnn::ns_run(b, n, m, 0, xyz1, xyz2, nullptr, nullptr, 0, dist, idx, workspace, workspace_bytes,
+                         to_stream(stream), 0, prcnn::EpiAffine{}, order1, order2);
+}
+
 extern "C" int prcnn_three_nn_interpolate_sorted(int b, int n, int m, int c, const float *xyz1,
                                                  const float *xyz2, const float *points2, float *out,
                                                  int64_t ldo, float *dist, int *idx, void *workspace,
@@ -782,14 +813,14 @@ extern "C" int prcnn_three_nn_interpolate_sorted(int b, int n, int m, int c, con
 int prcnn_ns_fused(int b, int n, int m, int c, const float *xyz1, const float *xyz2, const float *points2,
                    float *out, int64_t ldo, float *dist, int *idx, int epi, const prcnn::EpiAffine *aff,
                    void *ws, size_t ws_bytes,
-                   prcnn_stream_t stream)
+                   prcnn_stream_t stream, const int *order1, const int *order2)
 {
     if (b < 0 || n < 0 || m <= 0 || c <= 0 || ldo < c) return PRCNN_BAD_SHAPE;
     if (b == 0 || n == 0) return PRCNN_OK;
     if (!xyz1 || !xyz2 || !points2 || !out) return PRCNN_BAD_SHAPE;
     if (b > 65535) return PRCNN_UNSUPPORTED;
     return prcnn::ns_run(b, n, m, c, xyz1, xyz2, points2, out, ldo, dist, idx, ws, ws_bytes, to_stream(stream), epi,
-                         aff ? *aff : prcnn::EpiAffine{});
+                         aff ? *aff : prcnn::EpiAffine{}, order1, order2);
 }
 
 extern "C" size_t prcnn_query_ball_point_sorted_workspace_bytes(int b, int n, int m)
@@ -798,11 +829,27 @@ extern "C" size_t prcnn_query_ball_point_sorted_workspace_bytes(int b, int n, in
     return prcnn::ns_carve(nullptr, b, m, n).bytes;
 }
 
+extern "C" int prcnn_query_ball_point_msg_ordered(int b, int n, int m, int nscales, const float *host_radii,
+                                                  const int *host_nsamples, const float *xyz1,
+                                                  const float *xyz2, const int *order1, const int *order2,
+                                                  int *const *host_idx, int *const *host_pts_cnt, void *workspace,
+                                                  size_t workspace_bytes, prcnn_stream_t stream);
+
 extern "C" int prcnn_query_ball_point_msg_sorted(int b, int n, int m, int nscales, const float *host_radii,
                                                  const int *host_nsamples, const float *xyz1,
                                                  const float *xyz2, int *const *host_idx,
                                                  int *const *host_pts_cnt, void *workspace,
                                                  size_t workspace_bytes, prcnn_stream_t stream)
+{
+    return prcnn_query_ball_point_msg_ordered(b, n, m, nscales, host_radii, host_nsamples, xyz1, xyz2, nullptr,
+                                              nullptr, host_idx, host_pts_cnt, workspace, workspace_bytes, stream);
+}
+
+extern "C" int prcnn_query_ball_point_msg_ordered(int b, int n, int m, int nscales, const float *host_radii,
+                                                  const int *host_nsamples, const float *xyz1,
+                                                  const float *xyz2, const int *order1, const int *order2,
+                                                  int *const *host_idx, int *const *host_pts_cnt, void *workspace,
+                                                  size_t workspace_bytes, prcnn_stream_t stream)
 {
     using namespace prcnn;
     if (nscales < 1 || nscales > BQ_MAX_SCALES) return PRCNN_UNSUPPORTED;
@@ -823,5 +870,5 @@ extern "C" int prcnn_query_ball_point_msg_sorted(int b, int n, int m, int nscale
     for (int s = 0; s < nscales; ++s)
         if (!sc.idx[s]) return PRCNN_BAD_SHAPE;
     if (b > 65535) return PRCNN_UNSUPPORTED;
-    return bq_run(b, n, m, nscales, sc, xyz1, xyz2, workspace, workspace_bytes, to_stream(stream));
+    return bq_run(b, n, m, nscales, sc, xyz1, xyz2, workspace, workspace_bytes, to_stream(stream), order1, order2);
 }

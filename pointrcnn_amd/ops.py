@@ -162,9 +162,44 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
 BQ_SORTED_MIN_TESTS = 1 << 24
 
 
-def query_ball_point_msg(radius_list, nsample_list, xyz1, xyz2):
+def _check_order(order, b, n, m, what):
+    o1 = _dev(order[0], torch.int32, what + " order1", 2)
+    o2 = _dev(order[1], torch.int32, what + " order2", 2)
+    if tuple(o1.shape) != (b, n) or tuple(o2.shape) != (b, m):
+        raise ValueError("%s: order must be (order of xyz1 (b,n), order of xyz2 (b,m)) from grid_order" % what)
+    return o1, o2
+
+
+def grid_order(xyz1, xyz2):
+    """Grid orders of two point sets over their joint bounding box (prcnn_grid_order): the first pass of
+    every culled search over this pair, computed once.  Returns (order1 (b,n), order2 (b,m)) int32, to be
+    passed as `order=` to the searches over (xyz1, xyz2) -- swapped when the roles are swapped."""
+    xyz1 = _dev(xyz1, torch.float32, "grid_order xyz1", 3, 3)
+    xyz2 = _dev(xyz2, torch.float32, "grid_order xyz2", 3, 3)
+    if xyz1.shape[0] != xyz2.shape[0]:
+        raise ValueError("grid_order expects equal batch sizes")
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    o1 = torch.empty((b, n), dtype=torch.int32, device=xyz1.device)
+    o2 = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
+    _lib.check(_run("grid_order", {"bytes": b * 16 * (n + m)},
+                    lambda: _lib.lib().prcnn_grid_order(b, n, m, _p(xyz1), _p(xyz2), _p(o1), _p(o2), _stream())),
+               "grid_order")
+    return o1, o2
+
+
+def culled_pair(n, m, nsample_list=None):
+    """Whether the searches over point sets of n and m points per cloud take the culled (grid) path:
+    the ball query of m centroids in n points and the three_nn of n unknown among m known points."""
+    bq = (nsample_list is not None and BQ_SORTED_MIN_TESTS is not None and n * m >= BQ_SORTED_MIN_TESTS
+          and all(0 < int(ns) <= 64 for ns in nsample_list))
+    return bq, _use_sorted_nn(n, m)
+
+
+def query_ball_point_msg(radius_list, nsample_list, xyz1, xyz2, order=None):
     """All ball queries of one MSG level in a single pass (same results as one
-    query_ball_point call per radius).  Returns [(idx, pts_cnt), ...]."""
+    query_ball_point call per radius).  Returns [(idx, pts_cnt), ...].  order: grid_order(xyz1, xyz2)
+    computed beforehand (used by the culled path only)."""
     import ctypes
     xyz1 = _dev(xyz1, torch.float32, "QueryBallPoint xyz1", 3, 3)
     xyz2 = _dev(xyz2, torch.float32, "QueryBallPoint xyz2", 3, 3)
@@ -186,8 +221,9 @@ def query_ball_point_msg(radius_list, nsample_list, xyz1, xyz2):
             and all(0 < int(ns) <= 64 for ns in nsample_list)):
         nb = L.prcnn_query_ball_point_sorted_workspace_bytes(b, n, m)
         ws = torch.empty((nb,), dtype=torch.uint8, device=xyz1.device)
-        call = lambda: L.prcnn_query_ball_point_msg_sorted(b, n, m, k, radii, nss, _p(xyz1), _p(xyz2), idxs, cnts,
-                                                           _p(ws), nb, _stream())
+        o1, o2 = _check_order(order, b, n, m, "QueryBallPoint") if order is not None else (None, None)
+        call = lambda: L.prcnn_query_ball_point_msg_ordered(b, n, m, k, radii, nss, _p(xyz1), _p(xyz2), _p(o1), _p(o2),
+                                                            idxs, cnts, _p(ws), nb, _stream())
     else:
         call = lambda: L.prcnn_query_ball_point_msg(b, n, m, k, radii, nss, _p(xyz1), _p(xyz2), idxs, cnts, _stream())
     _lib.check(_run("query_ball_point", {"tests": b * m * n,
@@ -260,9 +296,10 @@ def _use_sorted_nn(n, m):
     return NN_SORTED_MIN_TESTS is not None and n * m >= NN_SORTED_MIN_TESTS and m >= NN_SORTED_MIN_M
 
 
-def three_nn(xyz1, xyz2):
+def three_nn(xyz1, xyz2, order=None):
     """tf_interpolate.py:9-18.  xyz1 (b,n,3) unknown, xyz2 (b,m,3) known ->
-    dist (b,n,3) f32 SQUARED distances, idx (b,n,3) int32."""
+    dist (b,n,3) f32 SQUARED distances, idx (b,n,3) int32.  order: grid_order(xyz1, xyz2) computed
+    beforehand (used by the culled path only)."""
     xyz1 = _dev(xyz1, torch.float32, "ThreeNN xyz1", 3, 3)             # tf_interpolate.cpp:163
     xyz2 = _dev(xyz2, torch.float32, "ThreeNN xyz2", 3, 3)             # tf_interpolate.cpp:168
     if xyz1.shape[0] != xyz2.shape[0]:
@@ -275,7 +312,9 @@ def three_nn(xyz1, xyz2):
     if _use_sorted_nn(n, m):
         nb = L.prcnn_three_nn_sorted_workspace_bytes(b, n, m)
         ws = torch.empty((nb,), dtype=torch.uint8, device=xyz1.device)
-        call = lambda: L.prcnn_three_nn_sorted(b, n, m, _p(xyz1), _p(xyz2), _p(dist), _p(idx), _p(ws), nb, _stream())
+        o1, o2 = _check_order(order, b, n, m, "ThreeNN") if order is not None else (None, None)
+        call = lambda: L.prcnn_three_nn_ordered(b, n, m, _p(xyz1), _p(xyz2), _p(o1), _p(o2), _p(dist), _p(idx), _p(ws), nb,
+                                                _stream())
     else:
         call = lambda: L.prcnn_three_nn(b, n, m, _p(xyz1), _p(xyz2), _p(dist), _p(idx), _stream())
     _lib.check(_run("three_nn", {"tests": b * n * m, "bytes": b * (12 * n + 12 * m + 24 * n)}, call), "ThreeNN")
@@ -428,9 +467,10 @@ def three_nn_interpolate_affine_supported(b, n, c1):
     return c1 <= 4 and not (FP_TWO_STEP_MAX_QUERIES is not None and b * n <= FP_TWO_STEP_MAX_QUERIES)
 
 
-def three_nn_interpolate_affine(xyz1, xyz2, points2, p1, u, t, relu=True):
+def three_nn_interpolate_affine(xyz1, xyz2, points2, p1, u, t, relu=True, order=None):
     """act(interpolate(points2) + p1 . u + t) -> (b,n,c) in one launch: the split first FP layer
-    whose points1 half is narrow (p1 (b,n,c1) with c1 <= 4, u (c1,c), t (c); p1 None: t only)."""
+    whose points1 half is narrow (p1 (b,n,c1) with c1 <= 4, u (c1,c), t (c); p1 None: t only).
+    order: grid_order(xyz1, xyz2) computed beforehand (used by the culled path only)."""
     xyz1 = _dev(xyz1, torch.float32, "three_nn_interpolate_affine xyz1", 3, 3)
     xyz2 = _dev(xyz2, torch.float32, "three_nn_interpolate_affine xyz2", 3, 3)
     points2 = _dev(points2, torch.float32, "three_nn_interpolate_affine points2", 3)
@@ -452,13 +492,16 @@ def three_nn_interpolate_affine(xyz1, xyz2, points2, p1, u, t, relu=True):
     out = torch.empty((b, n, c), dtype=torch.float32, device=xyz1.device)
     L = _lib.lib()
     ws, nb = None, 0
+    o1 = o2 = None
     if _use_sorted_nn(n, m):
         nb = L.prcnn_three_nn_sorted_workspace_bytes(b, n, m)
         ws = torch.empty((nb,), dtype=torch.uint8, device=xyz1.device)
+        if order is not None:
+            o1, o2 = _check_order(order, b, n, m, "three_nn_interpolate_affine")
     _lib.check(_run("three_nn_interpolate", {"tests": b * n * m,
                                              "bytes": b * (12 * n + 12 * m) + b * n * (16 * c + 4 * c1)},
-                    lambda: L.prcnn_three_nn_interpolate_affine(
-        b, n, m, c, _p(xyz1), _p(xyz2), _p(points2), _p(p1), c1, _p(u) if c1 else None, _p(t), _p(out), c,
+                    lambda: L.prcnn_three_nn_interpolate_affine_ordered(
+        b, n, m, c, _p(xyz1), _p(xyz2), _p(o1), _p(o2), _p(points2), _p(p1), c1, _p(u) if c1 else None, _p(t), _p(out), c,
         1 if relu else 0, _p(ws), nb, _stream())), "three_nn_interpolate_affine")
     return out
 

@@ -208,9 +208,10 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
 
 def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_list, is_training,
                            bn_decay, scope, bn=True, use_xyz=True, use_nchw=False, params=None,
-                           precision=None, new_xyz=None, balls=None):
+                           precision=None, new_xyz=None, balls=None, order=None):
     """models/pointnet_util.py:155-195 -> new_xyz (b,npoint,3), new_points (b,npoint,sum mlp[k][-1]).
-    Channel order inside each scale is [features, xyz_local] (:183)."""
+    Channel order inside each scale is [features, xyz_local] (:183).  order: ops.grid_order(xyz, new_xyz)
+    when the caller shares it with another search over the same two sets."""
     _check_inference(is_training)
     if use_nchw:
         raise NotImplementedError("use_nchw is never set by the reference's callers")
@@ -227,7 +228,7 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
     # pass them in (`balls`: [(idx, pts_cnt)] per scale, e.g. answered on another stream -- they
     # depend on coordinates only)
     if balls is None and FUSED:
-        balls = ops.query_ball_point_msg(radius_list, nsample_list, xyz, new_xyz)
+        balls = ops.query_ball_point_msg(radius_list, nsample_list, xyz, new_xyz, order=order)
     # SA_SPLIT: the first convolution is linear, so its feature half is evaluated once per POINT
     # for all scales together (b*n rows x c_feat x sum c1) instead of once per grouped row
     # (b*m*nsample rows per scale); the grouped layer then gathers those rows and adds the
@@ -335,10 +336,11 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
 
 
 def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True,
-                       params=None, precision=None, nn=None):
+                       params=None, precision=None, nn=None, order=None):
     """models/pointnet_util.py:198-228 -> (b, ndataset1, mlp[-1]).  `nn` = (idx, weight) of
     three_nn(xyz1, xyz2) + the inverse-distance weights (:210-214) when the caller has them
-    already (they depend on coordinates only)."""
+    already (they depend on coordinates only).  order: ops.grid_order(xyz1, xyz2) when the caller
+    shares it with another search over the same two sets."""
     _check_inference(is_training)
     store = params if params is not None else get_params()
     precision = PRECISION if precision is None else precision
@@ -370,7 +372,8 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
             # (p1 W_b) s + t is evaluated in the interpolation epilogue, never stored
             name = '%s/conv_0' % scope
             u = store.derived('__fpu/' + name, lambda: (W[c2:] * s.unsqueeze(0)).contiguous()) if c1 else None
-            x = ops.three_nn_interpolate_affine(xyz1, xyz2, y2.reshape(b, m, co), points1, u, t, relu=True)
+            x = ops.three_nn_interpolate_affine(xyz1, xyz2, y2.reshape(b, m, co), points1, u, t, relu=True,
+                                                order=order)
         else:
             if points1 is not None:
                 x = ops.mlp_layer(points1.reshape(b * n, c1), W[c2:], s, t, relu=False, precision=precision)

@@ -47,6 +47,20 @@ def sample_centroid_chain(l0_xyz, npoints, stream=None):
     return xs, evs
 
 
+# SHARE_ORDER: the level-1 ball query (points = the cloud, centroids = level-1 new_xyz) and the last FP
+# level's three_nn (unknown = the cloud, known = level-1 new_xyz) search the same two point sets; when
+# both take the culled path, the grid order is computed once (ops.grid_order) and handed to both.
+SHARE_ORDER = True
+
+
+def shared_order(l0_xyz, l1_xyz):
+    from . import ops
+    if not SHARE_ORDER:
+        return None
+    bq, nn = ops.culled_pair(l0_xyz.shape[1], l1_xyz.shape[1], RPN_SA[0][2])
+    return ops.grid_order(l0_xyz, l1_xyz) if bq and nn else None
+
+
 def rpn_geometry(l0_xyz, centroids):
     """Everything in the RPN stack that depends on coordinates only, given the four levels'
     centroids: the ball-query answers of every SA scale and, per FP level, three_nn + the
@@ -55,11 +69,12 @@ def rpn_geometry(l0_xyz, centroids):
                      "nn": [(idx, weight)] per FP level in call order (fa_layer2..5)}."""
     from . import ops
     xyzs = [l0_xyz] + list(centroids)
-    balls = [ops.query_ball_point_msg(radii, nsamples, xyzs[li], xyzs[li + 1])
+    order01 = shared_order(xyzs[0], xyzs[1])
+    balls = [ops.query_ball_point_msg(radii, nsamples, xyzs[li], xyzs[li + 1], order=order01 if li == 0 else None)
              for li, (_, radii, nsamples, _) in enumerate(RPN_SA)]
     nn = []
     for lo in (3, 2, 1, 0):
-        dist, idx = ops.three_nn(xyzs[lo], xyzs[lo + 1])
+        dist, idx = ops.three_nn(xyzs[lo], xyzs[lo + 1], order=order01 if lo == 0 else None)
         nn.append((idx, ops.fp_weights(dist)))
     return {"balls": balls, "nn": nn}
 
@@ -124,13 +139,21 @@ def rpn_sa_fp_stack(point_cloud, params=None, precision=None, is_training=False,
         pre, evs = list(centroids), None
     elif geometry_stream is not None:
         pre, evs = sample_centroid_chain(l0_xyz, [lv[0] for lv in RPN_SA], geometry_stream)
+    order01 = None
     for li, (npoint, radii, nsamples, mlps) in enumerate(RPN_SA):
         if evs is not None:
             torch.cuda.current_stream().wait_event(evs[li])
+        new_xyz = None if pre is None else pre[li]
+        if li == 0 and geometry is None and SHARE_ORDER:
+            if new_xyz is None:
+                from . import ops
+                new_xyz = ops.gather_point(l0_xyz, ops.farthest_point_sample(npoint, l0_xyz))
+            order01 = shared_order(l0_xyz, new_xyz)
         x, f = pointnet_sa_module_msg(xyzs[-1], feats[-1], npoint, radii, nsamples, mlps, is_training,
                                       bn_decay, scope='layer%d' % (li + 1), bn=True, params=params,
-                                      precision=precision, new_xyz=None if pre is None else pre[li],
-                                      balls=None if geometry is None else geometry["balls"][li])
+                                      precision=precision, new_xyz=new_xyz,
+                                      balls=None if geometry is None else geometry["balls"][li],
+                                      order=order01 if li == 0 else None)
         xyzs.append(x)
         feats.append(f)
     nn = [None] * 4 if geometry is None else geometry["nn"]
@@ -143,7 +166,8 @@ def rpn_sa_fp_stack(point_cloud, params=None, precision=None, is_training=False,
     # concat([l0_xyz, l0_points]) (models/rpn.py:191) is the input cloud itself
     p1 = point_cloud.contiguous()
     l0 = pointnet_fp_module(l0_xyz, xyzs[1], p1, l1, RPN_FP[3], is_training, bn_decay,
-                            scope='fa_layer5', bn=True, params=params, precision=precision, nn=nn[3])
+                            scope='fa_layer5', bn=True, params=params, precision=precision, nn=nn[3],
+                            order=order01)
     return l0, {"xyz": xyzs, "sa_feats": feats, "fp_feats": [l3, l2, l1, l0]}
 
 

@@ -367,6 +367,37 @@ def test_ball_query_culled_search_is_identical(cuda):
         ops.BQ_SORTED_MIN_TESTS = saved
 
 
+def test_shared_grid_order_gives_identical_results(cuda):
+    """prcnn_grid_order + the *_ordered entry points: one ordering pass shared by the level-1 ball query
+    (points = cloud, centroids = new_xyz) and the last FP level's three_nn (unknown = cloud, known =
+    new_xyz), roles swapped between the two: idx / pts_cnt / dist / interpolated values equal the calls
+    that order for themselves, bit for bit."""
+    g = torch.Generator().manual_seed(5)
+    pc = torch.as_tensor(S.kitti_batch(0, 5)).to(cuda)
+    xyz = pc[:, :, :3].contiguous()
+    new1 = ops.gather_point(xyz, ops.farthest_point_sample(4096, xyz))
+    assert ops.culled_pair(16384, 4096, [16, 32]) == (True, True)
+    order = ops.grid_order(xyz, new1)
+    assert order[0].shape == (5, 16384) and order[1].shape == (5, 4096)
+    for o, npts in zip(order, (16384, 4096)):       # each row is a permutation
+        assert torch.equal(torch.sort(o.long(), dim=1).values, torch.arange(npts, device=cuda).expand(5, npts))
+    ref = ops.query_ball_point_msg([0.1, 0.5], [16, 32], xyz, new1)
+    got = ops.query_ball_point_msg([0.1, 0.5], [16, 32], xyz, new1, order=order)
+    for (i0, c0), (i1, c1) in zip(ref, got):
+        assert torch.equal(i0, i1) and torch.equal(c0, c1)
+    d0, i0 = ops.three_nn(xyz, new1)
+    d1, i1 = ops.three_nn(xyz, new1, order=order)
+    assert torch.equal(d0, d1) and torch.equal(i0, i1)
+    f = torch.randn(5, 4096, 128, generator=g).to(cuda)
+    u = torch.randn(4, 128, generator=g).to(cuda)
+    t = torch.randn(128, generator=g).to(cuda)
+    a0 = ops.three_nn_interpolate_affine(xyz, new1, f, pc, u, t)
+    a1 = ops.three_nn_interpolate_affine(xyz, new1, f, pc, u, t, order=order)
+    assert torch.equal(a0, a1)
+    with pytest.raises(ValueError):
+        ops.three_nn(xyz, new1, order=(order[1], order[0]))
+
+
 @pytest.mark.parametrize("n,m,c,c1", [(40000, 300, 8, 1), (40000, 100, 8, 3), (36000, 260, 6, 1), (40000, 300, 12, 0)])
 def test_three_nn_interpolate_affine_equals_composition(cuda, n, m, c, c1):
     """Affine epilogue (split FP layer with a narrow points1) == interpolate, then add p1.u + t, ReLU;

@@ -425,9 +425,9 @@ def load_profile(name):
 
 # (kernel family, shape) -> entry of profiles/*_pmc_hot_kernels.json (tools/pmc_probe.py launches these shapes)
 PMC_KEYS = {
-    ("mlp_layer", "rows65536 K608 N256 pool1"): "mlp_kernel<2, 2, 2, 2, false, false, 16> grid_threads=262144",
-    ("mlp_layer", "rows262144 K260 N128 pool1"): "mlp_kernel<2, 2, 2, 2, false, false, 16> grid_threads=524288",
-    ("mlp_layer", "rows524288 K96 N128 pool32"): "mlp_kernel<2, 2, 2, 2, false, false, 16> grid_threads=1048576",
+    ("mlp_layer", "rows65536 K608 N256 pool1"): "mlp_kernel<2, 2, 2, 2, false, false, 32, false> grid_threads=262144",
+    ("mlp_layer", "rows262144 K260 N128 pool1"): "mlp_kernel<2, 2, 2, 2, false, false, 32, false> grid_threads=524288",
+    ("mlp_layer", "rows524288 K96 N128 pool32"): "mlp_kernel<2, 2, 2, 2, false, false, 16, false> grid_threads=1048576",
     ("sa_chain", "rows2097152 K4 N32-32-64 pool32"): "sa_chain_kernel<4, 32, 32, 64, 32, 32>",
     ("sa_chain2", "rows524288 N64-96-128 pool32"): "sa_chain2_kernel<96, 6>",
     ("mlp_layer", "rows4096 K512 N512 pool1"): "mlp_kernel<4, 1, 1, 2, false, false, 32, false> grid_threads=65536",
@@ -576,8 +576,9 @@ def main():
                 # from measured HBM traffic (PMC) where a committed pass covers the kernel, and is absent
                 # otherwise when the algorithmic rate is above the peak.
                 alg = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-                e.update(bound="hbm", achieved=round(alg, 3), peak=roofline.HBM_PEAK_GBS, unit="GB/s",
-                         frac_algorithmic=round(alg / roofline.HBM_PEAK_GBS, 4))
+                e.update(bound="hbm", achieved=round(alg, 3), peak=roofline.HBM_PEAK_GBS, unit="GB/s")
+                if alg <= roofline.HBM_PEAK_GBS:       # above the peak it is a cache-served rate, not a fraction of HBM
+                    e["frac_algorithmic"] = round(alg / roofline.HBM_PEAK_GBS, 4)
                 pe = pmc_entry(pmc, name, None)
                 if pe and pe.get("avg_us"):
                     e["frac"] = round(min(pe["hbm_bytes_corrected"] / (pe["avg_us"] * 1e-6) / 1e9 / roofline.HBM_PEAK_GBS, 1.0), 4)
@@ -622,7 +623,8 @@ def main():
             if best["bound"] == "hbm":
                 # an HBM-bound kernel's fraction comes from the measured traffic, never from gathered
                 # (cache-served) algorithmic bytes: a number above 1 is not a roofline fraction
-                roof["frac_algorithmic"] = roof["frac"]
+                if roof["frac"] <= 1.0:
+                    roof["frac_algorithmic"] = roof["frac"]
                 roof["frac"] = (round(min(traffic / (best["avg_launch_us"] * 1e-6) / 1e9 / best["peak"], 1.0), 4)
                                 if traffic else (roof["frac"] if roof["frac"] <= 1.0 else None))
                 if "gtests_per_s" in best:

@@ -500,7 +500,8 @@ def main():
     device = torch.device("cuda", local)
     precision = ops.PRECISION_FP32 if args.precision == "f32" else ops.PRECISION_BF16
     store = PU.ParamStore(seed=7, device=device)
-    pcs, prop = make_inputs(rank, device, args.batch)
+    # PRCNN_BENCH_INPUT_RANK: run rank r's scenes in a one-process run (tests compare them with the N > 1 job's)
+    pcs, prop = make_inputs(int(os.environ.get("PRCNN_BENCH_INPUT_RANK", rank)), device, args.batch)
     nstreams = max(1, args.streams)
     pipelined = not (args.no_graph or args.no_pipeline or args.geo_stream)
     group = max(1, args.fps_group) if pipelined else 1
@@ -665,7 +666,9 @@ def main():
                        "kernel_timing": "HIP events around every launch in an eager, single-stream instrumented "
                                         "pass of the same steps after the timed region",
                        "parallelism": "scene-sharded x%d" % world,
-                       "collective": "one RCCL all-gather of all detection records per timed region" if dist.is_initialized() else None},
+                       "collective": ("one %s all-gather of all detection records per timed region"
+                                      % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend() + " (rehearsal)")
+                                      if dist.is_initialized() else None)},
             "roofline": roof, "kernels": kernels, "fps": fps,
         }
         if not args.no_extras:

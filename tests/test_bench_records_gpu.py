@@ -46,3 +46,32 @@ def test_records_through_one_rank_rccl_group_equal_the_ungrouped_run(cuda, tmp_p
     # 6 steps with K % 4 != 0: units of 4 + eager remainder steps, and still one record per scene and step
     ids, counts = np.unique(rec1[:, 0], return_counts=True)
     assert list(ids) == list(range(16)) and (counts == 6).all()
+
+
+def test_two_rank_rehearsal_on_one_gpu_gathers_both_ranks_records(cuda, tmp_path):
+    """The N = 2 job as the driver launches it (torch.distributed.run, one process per rank), rehearsed on
+    ONE GPU: both ranks compute on cuda:0 and the group is gloo (RCCL wants a device per rank; the
+    collective call and everything around it are the same code).  Rank r owns scenes 16 r .. 16 r + 15;
+    the gathered records of each rank's scenes equal, bit for bit, the ungrouped run of that rank."""
+    out = str(tmp_path / "w2.npy")
+    env = dict(os.environ)
+    env.update({"PRCNN_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PRCNN_DIST_FORCE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29633", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
+           "--warmup", "3", "--no-cpu-baseline", "--no-extras", "--dump-records", out]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=170)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["replay_equals_eager"]
+    assert "gloo" in line["config"]["collective"]
+    rec = np.load(out)
+    assert rec.shape == (2 * 6 * 16, 802)
+    assert np.array_equal(rec[:, 0], np.sort(rec[:, 0], kind="stable"))          # ordered by scene id
+    for rank in (0, 1):
+        _, alone = _bench(tmp_path, "alone%d" % rank, {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0",
+                                                                 "PRCNN_BENCH_INPUT_RANK": str(rank)})
+        mine = rec[(rec[:, 0] >= 16 * rank) & (rec[:, 0] < 16 * rank + 16)]
+        assert mine.shape == alone.shape
+        assert np.array_equal(mine, alone[np.argsort(alone[:, 0], kind="stable")])

@@ -630,10 +630,17 @@ static int sa_add_mlp2_pool_impl(int b, int n, int m, int nsample, const float *
     hipStream_t st = to_stream(stream);
     const long long tiles = (rows + 31) / 32;
     static const int nw_env = getenv("PRCNN_CHAIN2_NW") ? atoi(getenv("PRCNN_CHAIN2_NW")) : 0;   // tuning aid
+    // At most 128 workgroups, i.e. half the CUs: a workgroup takes ~150 KB of a CU's LDS, so while one is resident
+    // no other kernel's workgroup fits beside it, although its 6 - 12 waves leave most of the CU's issue slots idle.
+    // With another batch in flight on a second stream (the bench's schedule) 256 workgroups stall that stream for
+    // the launch's whole duration: 10 986 / 11 056 scenes/s with 256, 11 212 - 11 272 with 128 (64 .. 160 alike;
+    // the same cap on sa_chain, whose workgroups are small, gains nothing).  Alone the launch is slower with 128
+    // (tools/step_table.py); PRCNN_CHAIN2_BLOCKS overrides.
+    static const int max_blocks = getenv("PRCNN_CHAIN2_BLOCKS") ? atoi(getenv("PRCNN_CHAIN2_BLOCKS")) : 128;
 #define PRCNN_CHAIN2_LAUNCH(C2P_, NW_)                                                                  \
     do {                                                                                                \
         long long blocks = (tiles + NW_ - 1) / NW_;                                                     \
-        if (blocks > 256) blocks = 256;              /* weights are loaded once per workgroup */       \
+        if (blocks > max_blocks) blocks = max_blocks; /* weights are loaded once per workgroup */      \
         hipLaunchKernelGGL((sa_chain2_kernel<C2P_, NW_>), dim3((unsigned)blocks), dim3(NW_ * 64), 0, st, a); \
     } while (0)
     if (c2 <= 64) {

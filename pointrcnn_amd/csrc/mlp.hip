@@ -396,7 +396,7 @@ __device__ __forceinline__ void mlp_tile(const MlpArgs &a, const long long row_b
 // the capacity's worth of workgroups only to have them leave costs ~0.1 us each: 100 us at 32768
 // rows of capacity, measured).
 template <int WM, int WN, int TM, int TN, bool GATHER, bool BF16, int KB, bool ADD = false>
-__global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void mlp_kernel(const MlpArgs a)
+__global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu((BF16 || GATHER) && TM * TN == 4 ? 3 : 4, 8))) void mlp_kernel(const MlpArgs a)
 {
     mlp_tile<WM, WN, TM, TN, GATHER, BF16, KB, ADD>(a, blockIdx.x, a.rows);
 }

@@ -335,6 +335,9 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
     return new_xyz, out
 
 
+DEBUG_TAP = None
+
+
 def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True,
                        params=None, precision=None, nn=None, order=None):
     """models/pointnet_util.py:198-228 -> (b, ndataset1, mlp[-1]).  `nn` = (idx, weight) of
@@ -372,8 +375,11 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
             # (p1 W_b) s + t is evaluated in the interpolation epilogue, never stored
             name = '%s/conv_0' % scope
             u = store.derived('__fpu/' + name, lambda: (W[c2:] * s.unsqueeze(0)).contiguous()) if c1 else None
+            y2_before = y2.clone() if DEBUG_TAP is not None else None
             x = ops.three_nn_interpolate_affine(xyz1, xyz2, y2.reshape(b, m, co), points1, u, t, relu=True,
                                                 order=order)
+            if DEBUG_TAP is not None:      # diagnostic: keep the level's intermediates (bench.py PRCNN_BENCH_TAP)
+                DEBUG_TAP.append((scope, y2, x, y2_before, y2.clone()))
         else:
             if points1 is not None:
                 x = ops.mlp_layer(points1.reshape(b * n, c1), W[c2:], s, t, relu=False, precision=precision)

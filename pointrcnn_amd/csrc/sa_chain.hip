@@ -636,7 +636,10 @@ static int sa_add_mlp2_pool_impl(int b, int n, int m, int nsample, const float *
     // the launch's whole duration: 10 986 / 11 056 scenes/s with 256, 11 212 - 11 272 with 128 (64 .. 160 alike;
     // the same cap on sa_chain, whose workgroups are small, gains nothing).  Alone the launch is slower with 128
     // (tools/step_table.py); PRCNN_CHAIN2_BLOCKS overrides.
-    static const int max_blocks = getenv("PRCNN_CHAIN2_BLOCKS") ? atoi(getenv("PRCNN_CHAIN2_BLOCKS")) : 128;
+    // Only with class lists (few tiles per workgroup either way); the plain layout has eight times the tiles and
+    // keeps one workgroup per CU (no-dedup step: 6217 scenes/s with 256, 5998 with 128).
+    static const int blocks_env = getenv("PRCNN_CHAIN2_BLOCKS") ? atoi(getenv("PRCNN_CHAIN2_BLOCKS")) : 0;
+    const int max_blocks = blocks_env > 0 ? blocks_env : (cls_list ? 128 : 256);
 #define PRCNN_CHAIN2_LAUNCH(C2P_, NW_)                                                                  \
     do {                                                                                                \
         long long blocks = (tiles + NW_ - 1) / NW_;                                                     \

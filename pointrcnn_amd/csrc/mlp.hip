@@ -442,6 +442,11 @@ static int launch_mlp(const MlpArgs &a, hipStream_t st)
     // amortise the A staging best when K is large or the grid is many rounds deep; 64 columns
     // (4 waves/SIMD instead of 3, twice the workgroups) win on shallow grids; never pad a
     // narrow layer up to a wide tile.
+    // diagnostic (PRCNN_BF16_MASK): run classes of bf16 launches in fp32 instead -- 1: 128-wide dense tiles, 2: narrower
+    // dense tiles, 4: gather / gather-add prologues, 8: compacted rows
+    static const int bf16_mask = getenv("PRCNN_BF16_MASK") ? atoi(getenv("PRCNN_BF16_MASK")) : 15;
+    if (BF16 && GATHER && !(bf16_mask & 4)) return launch_mlp<GATHER, false>(a, st);
+    if (BF16 && !GATHER && a.rows_dev && !(bf16_mask & 8)) return launch_mlp<GATHER, false>(a, st);
     if (GATHER && a.add) {
         // gather + 3-column product: memory-bound, the narrow tiles (no spills with the gather
         // epilogue) are the right ones whatever cout is
@@ -467,6 +472,7 @@ static int launch_mlp(const MlpArgs &a, hipStream_t st)
     else if (wgs128 < 256) bn = rb * ((a.cout + 63) / 64) < 256 ? 32 : 64;
     else bn = 128;      // at 4 waves/SIMD the 128-wide tile wins from one workgroup per CU on (sweep 2)
     if (const char *f = getenv("PRCNN_MLP_BN")) bn = atoi(f);   // tuning aid (32 / 64 / 128)
+    if (BF16 && !GATHER && !a.rows_dev && !(bf16_mask & (bn == 128 ? 1 : 2))) return launch_mlp<GATHER, false>(a, st);
     // measured (profiles/r01_mlp_tile_sweep.txt): 32-deep fp32 chunks do not pay (the kernel is
     // MFMA-issue bound, not barrier bound), so fp32 stays at 16
     int kb = BF16 ? 32 : 16;

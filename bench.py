@@ -314,8 +314,11 @@ class PipelinedSchedule:
     def run(self, k, ring):
         plan = [self.group] * (k // self.group) + [1] * (k % self.group)
         pos = 0
+        stagger = float(os.environ.get("PRCNN_BENCH_STAGGER_MS", "0"))    # probe: offset the second stream's units
         for u, G in enumerate(plan):
             j = u % len(self.streams)
+            if stagger > 0 and u == 1:
+                time.sleep(stagger * 1e-3)
             unit = self.units[j] if G == self.group else self.rem[j]
             with torch.cuda.stream(self.streams[j]):
                 for _, rec in unit.run():

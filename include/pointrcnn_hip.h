@@ -371,7 +371,10 @@ int prcnn_query_ball_point_msg_sorted(int b, int n, int m, int nscales, const fl
  * their own ordering pass.  order1 (b,n) / order2 (b,m): point indices of xyz1 / xyz2 in grid
  * order (the order inside a cell is unspecified; no result depends on it).  The *_ordered entry
  * points take (order1, order2) for THEIR (xyz1, xyz2): swap the two when the roles are swapped.
- * Both NULL = same as the entry point without the suffix.  Results are bit-identical either way. */
+ * Both NULL = same as the entry point without the suffix.  Results are bit-identical either way.
+ * The arrays must be what prcnn_grid_order wrote for this (b, n, m) and these coordinates, on the
+ * same stream or ordered after it: their entries are used as gather indices into xyz1 / xyz2 and are
+ * NOT range-checked (an array from elsewhere is a caller error like a wrong pointer). */
 int prcnn_grid_order(int b, int n, int m, const float *xyz1, const float *xyz2, int *order1,
                      int *order2, prcnn_stream_t stream);
 int prcnn_three_nn_ordered(int b, int n, int m, const float *xyz1, const float *xyz2,

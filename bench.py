@@ -86,9 +86,22 @@ def ahead_work(pcs_next, cent_next, group):
     xyz_next = pcs_next[:, :, 0:3].contiguous()
     if group > 1:
         xyz_next = xyz_next.repeat(group, 1, 1)              # synthetic input: the same batch again
-    xs, _ = stacks.sample_centroid_chain(xyz_next, [lv[0] for lv in stacks.RPN_SA])
+    npoints = [lv[0] for lv in stacks.RPN_SA]
+    # The chain runs beside the feature phases of two streams: level 1 on the sampler that leaves its
+    # CU to them (prcnn_farthest_point_sample_shared; PRCNN_BENCH_FPS_SHARED=0: the register-resident one).
+    shared = os.environ.get("PRCNN_BENCH_FPS_SHARED", "1") != "0"
+    probe = os.environ.get("PRCNN_BENCH_PROBE_NO_FPS")        # probes only (not valid bench lines)
+    if probe == "2":                                          # levels 2.. only (level 1 keeps its centroids)
+        xs = [cent_next[0]] + stacks.sample_centroid_chain(cent_next[0], npoints[1:], shared=shared)[0]
+    elif probe == "4":                                        # the fork / join and the copies alone: no sampling
+        xs = [c + 0.0 for c in cent_next]
+    elif probe == "3":                                        # level 1 only
+        xs = stacks.sample_centroid_chain(xyz_next, npoints[:1], shared=shared)[0]
+    else:
+        xs, _ = stacks.sample_centroid_chain(xyz_next, npoints, shared=shared)
     for dst, x in zip(cent_next, xs):
-        dst.copy_(x)
+        if dst is not x:
+            dst.copy_(x)
 
 
 def feature_work(pcs_cur, prop, store, precision, cent_cur, group):
@@ -191,6 +204,20 @@ def time_hbm_copy(device, mbytes=1024, iters=10):
     e1.record()
     torch.cuda.synchronize()
     return 2.0 * (mbytes << 20) * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def time_fps_shared(pcs, m=4096):
+    """Level-1 sampling of the bench batch on the small-footprint sampler the pipelined schedule uses
+    (alone on the GPU: slower per iteration than the register-resident kernel, see `fps`)."""
+    xyz = pcs[:, :, 0:3].contiguous()
+    ops.farthest_point_sample(m, xyz, shared=True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ops.farthest_point_sample(m, xyz, shared=True)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    return {"ms": round(ms, 3), "us_per_iteration": round(1e3 * ms / (m - 1), 4)}
 
 
 def time_fps_dense(device, n=131072, m=16384):
@@ -620,6 +647,8 @@ def main():
         for name, d in ksum.items():
             e = {"launches": d["launches"], "ms_total": round(d["ms"], 3),
                  "avg_us": round(1e3 * d["ms"] / d["launches"], 2)}
+            if d.get("stalled"):
+                e["host_stalled_samples"] = d["stalled"]      # replaced by their shape's median (KernelTimer.summary)
             if "flops" in d:
                 e.update(bound="mfma", achieved=round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 3), peak=peak_mfma, unit="TFLOP/s")
                 e["frac"] = round(e["achieved"] / e["peak"], 4)
@@ -712,6 +741,9 @@ def main():
                        "batch_per_gpu": args.batch, "points": NPTS, "streams": n_streams_used,
                        "hip_graph": hip_graph, "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 3),
                        "geometry_streams": bool(args.geo_stream), "fps_one_step_ahead": bool(pipelined),
+                       "fps_level1_sampler": (("shared (L2-resident buckets, 4 waves per cloud)"
+                                               if os.environ.get("PRCNN_BENCH_FPS_SHARED", "1") != "0"
+                                               else "register-resident (one CU per cloud)") if pipelined else "register-resident (one CU per cloud)"),
                        "duplicate_free_groups": bool(PU.SA_DEDUP), "ball_fill": ball_fill(pcs),
                        "batches_per_replay": group, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "eager_remainder_steps": (args.steps % group) if pipelined else 0,
                        "replay_equals_eager": replay_ok, "replay_diff": replay_diff,
@@ -724,6 +756,8 @@ def main():
             "roofline": roof, "kernels": kernels, "fps": fps,
         }
         if not args.no_extras:
+            if fps is not None:
+                fps["level1_shared_sampler"] = time_fps_shared(pcs)
             nms_ms, nms_keep = time_nms(device)
             hbm_copy = time_hbm_copy(device)
             out.update({

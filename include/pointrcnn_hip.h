@@ -71,6 +71,18 @@ int prcnn_farthest_point_sample(int b, int n, int m, const float *inp, float *te
                                 int *out, prcnn_stream_t stream);
 size_t prcnn_fps_temp_bytes(int b, int n);
 
+/* The same sampling (same launcher, tf_sampling.cpp:94 / tf_sampling_g.cu:105-170: identical
+ * indices) for callers that keep OTHER kernels in flight beside it.  prcnn_farthest_point_sample
+ * holds a cloud in one CU's registers and LDS for the whole chain, so that CU serves nothing else
+ * meanwhile; this variant keeps the cloud in `temp` (L2-resident, sorted into buckets of
+ * neighbouring points by a short first launch) and samples with four waves and ~50 registers per
+ * cloud, which fit beside any other kernel's waves.  Alone it is slower per iteration (one more
+ * L2 round trip); n <= 16384.  `temp`: prcnn_fps_shared_temp_bytes(b, n) bytes, 16-byte aligned,
+ * overwritten by the call (no state is kept in it between calls). */
+size_t prcnn_fps_shared_temp_bytes(int b, int n);
+int prcnn_farthest_point_sample_shared(int b, int n, int m, const float *inp, void *temp,
+                                       size_t temp_bytes, int *out, prcnn_stream_t stream);
+
 /* gatherpointLauncher(int b,int n,int m,const float* inp,const int* idx,float* out)
  *   tf_sampling.cpp:125, tf_sampling_g.cu:172-181.  out[b,j,:] = inp[b,idx[b,j],:], C=3 */
 int prcnn_gather_point(int b, int n, int m, const float *inp, const int *idx, float *out,

@@ -25,6 +25,8 @@ SIGNATURES = {
     "prcnn_last_hip_error_string": (_c.c_char_p, []),
     "prcnn_farthest_point_sample": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "prcnn_fps_temp_bytes": (_sz, [_i, _i]),
+    "prcnn_fps_shared_temp_bytes": (_sz, [_i, _i]),
+    "prcnn_farthest_point_sample_shared": (_i, [_i, _i, _i, _vp, _vp, _sz, _vp, _vp]),
     "prcnn_gather_point": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "prcnn_query_ball_point": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "prcnn_query_ball_point_msg": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpointrcnn_hip.so")
-SOURCES = ["c_api.hip", "fps.hip", "grouping.hip", "interp.hip", "nms_rotate.hip", "mlp.hip", "sa_chain.hip", "grad.hip", "nn_sorted.hip", "detections.hip", "knn.hip", "rpn_head.hip"]
+SOURCES = ["c_api.hip", "fps.hip", "fps_bucket.hip", "grouping.hip", "interp.hip", "nms_rotate.hip", "mlp.hip", "sa_chain.hip", "grad.hip", "nn_sorted.hip", "detections.hip", "knn.hip", "rpn_head.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
          "-Wall", "-Wno-unused-function"]
 # per-file extra flags (measured choices)
@@ -21,7 +21,8 @@ EXTRA = {}
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
-    deps = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "pointrcnn_hip.h")]
+    deps = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "fps_sort.h"),
+            os.path.join(HERE, "..", "include", "pointrcnn_hip.h")]
     procs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

@@ -9,6 +9,8 @@ current torch stream (no eager fallback; a missing library or a CPU tensor raise
 Shape errors raise ValueError, mirroring the OP_REQUIRES checks of the reference's
 tf_*.cpp shims.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -35,14 +37,27 @@ class KernelTimer:
         return rc
 
     def summary(self, by_shape=False):
-        """Per kernel family (or, with by_shape, per (family, identical work) = per shape)."""
+        """Per kernel family (or, with by_shape, per (family, identical work) = per shape).
+        An interval between two events also holds whatever the HOST did between recording the first
+        and launching the kernel (a garbage collection, a page fault: tens of ms on an idle stream), so a
+        sample above 3x the median of its own shape is replaced by that median (`stalled` counts them)."""
         torch.cuda.synchronize()
+        shape_of = lambda name, work: (name, tuple(sorted((k, v) for k, v in work.items() if not callable(v))))
+        times = {}
+        for name, work, s, e in self.records:
+            times.setdefault(shape_of(name, work), []).append(s.elapsed_time(e))
+        median = {k: sorted(v)[len(v) // 2] for k, v in times.items()}
         out = {}
         for name, work, s, e in self.records:
-            key = (name, tuple(sorted((k, v) for k, v in work.items() if not callable(v)))) if by_shape else name
-            d = out.setdefault(key, {"launches": 0, "ms": 0.0})
+            shape = shape_of(name, work)
+            key = shape if by_shape else name
+            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "stalled": 0})
             d["launches"] += 1
-            d["ms"] += s.elapsed_time(e)
+            t = s.elapsed_time(e)
+            if len(times[shape]) >= 3 and t > 3.0 * median[shape]:
+                t = median[shape]
+                d["stalled"] += 1
+            d["ms"] += t
             for k, v in work.items():
                 if callable(v):          # evaluated after the launch finished (data-dependent work)
                     v = v()
@@ -93,8 +108,17 @@ def _p(t):
 
 # ---- sampling ---------------------------------------------------------------------------
 
-def farthest_point_sample(npoint, inp, check=False):
+# PRCNN_FPS_SHARED=1: long chains over 4096 < n <= 16384 points (the first RPN level) run on the
+# small-footprint sampler (prcnn_farthest_point_sample_shared: same indices, the cloud in L2 instead
+# of one CU's registers), for callers that keep other kernels in flight beside the chain.
+FPS_SHARED = os.environ.get("PRCNN_FPS_SHARED", "0") == "1"
+FPS_SHARED_MIN_N = int(os.environ.get("PRCNN_FPS_SHARED_MIN_N", "4097"))
+
+
+def farthest_point_sample(npoint, inp, check=False, shared=None):
     """tf_sampling.py:49-57.  inp (b,n,3) f32 -> (b,npoint) int32.
+    shared=True (default: FPS_SHARED, for 4096 < n <= 16384 and npoint >= 256): the sampler that
+    leaves its CU to other kernels (n <= 16384), bit-identical indices.
     Clouds of more than 16384 points are sampled by several cooperating workgroups, which can
     fail (bounded wait for a partner that never became resident: see prcnn_farthest_point_sample);
     the result then carries `fps_error`, a 1-element int32 GPU tensor that is 0 on success (an
@@ -105,6 +129,17 @@ def farthest_point_sample(npoint, inp, check=False):
     npoint = int(npoint)
     out = torch.empty((b, max(npoint, 0)), dtype=torch.int32, device=inp.device)
     L = _lib.lib()
+    if shared is None:
+        shared = FPS_SHARED and FPS_SHARED_MIN_N <= n <= 16384 and npoint >= 256
+    if shared:
+        tb = L.prcnn_fps_shared_temp_bytes(b, n)
+        temp = torch.empty(max(tb, 16), dtype=torch.uint8, device=inp.device)
+        _lib.check(_run("fps", {"iters": max(npoint - 1, 0), "dist_evals": b * max(npoint - 1, 0) * n,
+                                 "bytes": b * (12 * n + 4 * npoint)},
+                        lambda: L.prcnn_farthest_point_sample_shared(b, n, npoint, _p(inp), _p(temp), tb, _p(out),
+                                                                     _stream())),
+                   "FarthestPointSample (shared)")
+        return out
     tb = L.prcnn_fps_temp_bytes(b, n)
     temp = torch.empty(tb // 4, dtype=torch.float32, device=inp.device) if tb else None
     _lib.check(_run("fps", {"iters": max(npoint - 1, 0), "dist_evals": b * max(npoint - 1, 0) * n,

@@ -23,11 +23,13 @@ RPN_SA = [
 RPN_FP = [[512, 512], [512, 512], [256, 256], [128, 128]]
 
 
-def sample_centroid_chain(l0_xyz, npoints, stream=None):
+def sample_centroid_chain(l0_xyz, npoints, stream=None, shared=None):
     """FPS + gather for every level: l0 -> l1 -> ... depends on coordinates only, so the
     whole (strictly serial, latency-bound) chain can run on a side stream while the main
     stream does the feature work of the levels already sampled.  Returns the list of
-    new_xyz tensors and one event per level recorded on `stream`."""
+    new_xyz tensors and one event per level recorded on `stream`.
+    shared=True: long chains over 4096 < n <= 16384 points (level 1) run on the small-footprint
+    sampler, which leaves its CU to the kernels in flight beside it (same indices; slower alone)."""
     from . import ops
     xs, evs = [], []
     cur = torch.cuda.current_stream()
@@ -37,7 +39,8 @@ def sample_centroid_chain(l0_xyz, npoints, stream=None):
     with torch.cuda.stream(side):
         x = l0_xyz
         for m in npoints:
-            x = ops.gather_point(x, ops.farthest_point_sample(m, x))
+            sh = (shared and 4096 < x.shape[1] <= 16384 and m >= 256) if shared is not None else None
+            x = ops.gather_point(x, ops.farthest_point_sample(m, x, shared=sh))
             xs.append(x)
             if stream is not None:
                 ev = torch.cuda.Event()

@@ -95,6 +95,9 @@ def ahead_work(pcs_next, cent_next, group):
         xs = [cent_next[0]] + stacks.sample_centroid_chain(cent_next[0], npoints[1:], shared=shared)[0]
     elif probe == "4":                                        # the fork / join and the copies alone: no sampling
         xs = [c + 0.0 for c in cent_next]
+    elif probe == "5":                                        # an (almost) empty side branch
+        cent_next[-1].add_(0.0)
+        return
     elif probe == "3":                                        # level 1 only
         xs = stacks.sample_centroid_chain(xyz_next, npoints[:1], shared=shared)[0]
     else:
@@ -122,25 +125,40 @@ def pipelined_step(pcs_cur, pcs_next, prop, store, precision, cent_cur, cent_nex
     same whatever the number of clouds, 16 CUs per batch) never gates full-chip work, and one
     chain's latency is spread over `group` batches.  Returns one (feats, rec) per batch."""
     cur = torch.cuda.current_stream()
+    probe = os.environ.get("PRCNN_BENCH_PROBE_NO_FPS")        # probes only (not valid bench lines)
+    if probe == "1":                                          # feature phases alone: no fork, no copies
+        return feature_work(pcs_cur, prop, store, precision, cent_cur, group)
+    if probe == "6":                                          # no fork; the copies on the main stream
+        outs = feature_work(pcs_cur, prop, store, precision, cent_cur, group)
+        for dst, src in zip(cent_cur, cent_next):
+            dst.copy_(src)
+        return outs
     side.wait_stream(cur)
-    if os.environ.get("PRCNN_BENCH_PROBE_NO_FPS") != "1":     # probe only: feature phases alone (not a valid bench line)
-        with torch.cuda.stream(side):
-            ahead_work(pcs_next, cent_next, group)
+    with torch.cuda.stream(side):
+        ahead_work(pcs_next, cent_next, group)
     outs = feature_work(pcs_cur, prop, store, precision, cent_cur, group)
     cur.wait_stream(side)
-    for dst, src in zip(cent_cur, cent_next):
-        dst.copy_(src)
+    if probe != "5":
+        for dst, src in zip(cent_cur, cent_next):
+            dst.copy_(src)
     return outs
 
 
 class Unit:
-    """One replayable unit of the pipelined schedule on one stream: `group` batches, as a HIP graph
-    (graph=True) or issued eagerly.  The unit OWNS every tensor its graph reads or writes (the
-    centroid sets, the outputs) for as long as the graph lives."""
+    """One replayable unit of the pipelined schedule on one stream: `group` batches, as HIP graphs
+    (graph=True) or issued eagerly.  The unit OWNS every tensor its graphs read or write (the
+    centroid sets, the outputs) for as long as the graphs live.
+    PRCNN_BENCH_SPLIT=1: the feature phases and the sampling chain as TWO linear graphs, replayed on
+    the step stream and its companion stream and joined by stream events, instead of ONE graph that
+    holds the fork and the join.  Measured: both forms reach the same rate when every
+    one of the four lanes (2 x features, 2 x chain) has a hardware queue to itself -- the single graph
+    with HIP's default 4 queues, the two graphs with 8 -- and both lose a third (8.2 - 8.5 k scenes/s)
+    with the other queue count, where a chain shares a queue with the other stream's features."""
 
     def __init__(self, st, side, pcs, prop, store, precision, group, graph=True):
         self.st, self.side, self.group = st, side, group
         self.args = (pcs, pcs, prop, store, precision)
+        self.split = os.environ.get("PRCNN_BENCH_SPLIT", "0") == "1" and os.environ.get("PRCNN_BENCH_PROBE_NO_FPS") not in ("1", "6")
         with torch.cuda.stream(st):
             xyz_rep = pcs[:, :, 0:3].contiguous().repeat(group, 1, 1)
             xs, _ = stacks.sample_centroid_chain(xyz_rep, [lv[0] for lv in stacks.RPN_SA])
@@ -148,15 +166,32 @@ class Unit:
             self.cent_next = [x.clone() for x in xs]
             self.outs = pipelined_step(*self.args, self.cent_cur, self.cent_next, side, group)   # warm-up
         torch.cuda.synchronize()
-        self.graph = None
-        if graph:
+        self.graph = self.g_chain = self.g_feat = None
+        if graph and self.split:
+            self.g_chain = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_chain, stream=side):
+                ahead_work(pcs, self.cent_next, group)
+            self.g_feat = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_feat, stream=st):
+                self.outs = feature_work(pcs, prop, store, precision, self.cent_cur, group)
+        elif graph:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=st):
                 self.outs = pipelined_step(*self.args, self.cent_cur, self.cent_next, side, group)
 
     def run(self):
         """Issue the unit on its stream (the caller has made it current)."""
-        if self.graph is not None:
+        if self.g_feat is not None:
+            cur = torch.cuda.current_stream()
+            self.side.wait_stream(cur)              # the previous unit's copy out of cent_next has been issued on cur
+            with torch.cuda.stream(self.side):
+                self.g_chain.replay()
+            self.g_feat.replay()
+            cur.wait_stream(self.side)
+            if os.environ.get("PRCNN_BENCH_PROBE_NO_FPS") != "5":
+                for dst, src in zip(self.cent_cur, self.cent_next):
+                    dst.copy_(src)
+        elif self.graph is not None:
             self.graph.replay()
         else:
             self.outs = pipelined_step(*self.args, self.cent_cur, self.cent_next, self.side, self.group)

@@ -28,6 +28,7 @@ constexpr int FB_NBUCKET = FB_CAP / FB_BUCKET;
 
 typedef float fb_f4 __attribute__((ext_vector_type(4)));
 typedef int fb_i2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct FbWs {
     fb_f4 *pts;      // (b, FB_CAP): x, y, z, tie-break key (int bits) in sorted order; padding slots zero
@@ -127,30 +128,17 @@ __global__ __launch_bounds__(NW * 64) void fb_sample_kernel(int n, int m, const 
             Nk = ~k0;
         }
     }
-    // maximum of (Tv signed : Nk unsigned) over the bucket lanes -> packed slot value of this wave
+    // maximum of (Tv signed : Nk unsigned) over the bucket lanes -> packed slot value of this wave:
+    // the largest Tv first (one 32-bit DPP reduction), then the largest Nk among its holders
+    // (mostly a single lane: one readlane)
     auto wave_best = [&](unsigned &hiw, unsigned &low) {
-        long long v = ((long long)Tv << 32) | (unsigned)Nk;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {                       // all-reduce inside each row of 16 lanes
-            int ol, oh;
-            if (st == 0) { ol = dpp_i32<0xB1>((int)v, (int)v); oh = dpp_i32<0xB1>((int)(v >> 32), (int)(v >> 32)); }
-            else if (st == 1) { ol = dpp_i32<0x4E>((int)v, (int)v); oh = dpp_i32<0x4E>((int)(v >> 32), (int)(v >> 32)); }
-            else if (st == 2) { ol = dpp_i32<0x141>((int)v, (int)v); oh = dpp_i32<0x141>((int)(v >> 32), (int)(v >> 32)); }
-            else { ol = dpp_i32<0x140>((int)v, (int)v); oh = dpp_i32<0x140>((int)(v >> 32), (int)(v >> 32)); }
-            const long long o = ((long long)oh << 32) | (unsigned)ol;
-            v = o > v ? o : v;
-        }
-        long long best = ((long long)__builtin_amdgcn_readlane((int)(v >> 32), 0) << 32) |
-                         (unsigned)__builtin_amdgcn_readlane((int)v, 0);
-#pragma unroll
-        for (int row = 1; row < (BPW + 15) / 16; ++row) {      // rows of 16 bucket lanes beyond the first
-            const long long o = ((long long)__builtin_amdgcn_readlane((int)(v >> 32), row * 16) << 32) |
-                                (unsigned)__builtin_amdgcn_readlane((int)v, row * 16);
-            best = o > best ? o : best;
-        }
-        const int bt = (int)(best >> 32);
-        low = (unsigned)best;
-        hiw = bt < 0 ? 0u : (unsigned)bt + 1u;                 // fps_pack (fps.hip)
+        const int tmax = wave_max_i32(Tv);                     // lanes >= BPW hold INT_MIN
+        const unsigned long long holders = __ballot(Tv == tmax);
+        if ((holders & (holders - 1)) == 0)
+            low = (unsigned)__builtin_amdgcn_readlane(Nk, __builtin_ctzll(holders));
+        else                                                    // unsigned max through the signed reduction
+            low = (unsigned)wave_max_i32(Tv == tmax ? (int)((unsigned)Nk ^ 0x80000000u) : (int)0x80000000) ^ 0x80000000u;
+        hiw = tmax < 0 ? 0u : (unsigned)tmax + 1u;             // fps_pack (fps.hip)
     };
     unsigned wb_hi, wb_lo;
     wave_best(wb_hi, wb_lo);
@@ -159,6 +147,11 @@ __global__ __launch_bounds__(NW * 64) void fb_sample_kernel(int n, int m, const 
     int old = 0;                                               // wave-uniform
     __syncthreads();
 
+    struct Bucket {              // this lane's pair of points of one bucket, as loaded
+        fb_f4 c0, c1;
+        fb_i2 t;
+        int p, r0;
+    };
     for (int j = 1; j < m; ++j) {
         const float x1 = cdata[old * 3 + 0], y1 = cdata[old * 3 + 1], z1 = cdata[old * 3 + 2];
         // lower bound of the distance from the sample to the box of bucket `lane`
@@ -170,35 +163,27 @@ __global__ __launch_bounds__(NW * 64) void fb_sample_kernel(int n, int m, const 
         if (BPW < 64) dm &= (1ull << (BPW & 63)) - 1ull;       // (lanes >= BPW hold INT_MIN and never vote)
         if (dm) {
             bool changed = false;
-            int p = __builtin_ctzll(dm);
-            dm &= dm - 1;
-            int r0 = slot_of(p);
-            fb_f4 a0 = pts[r0], a1 = pts[r0 + 1];
-            fb_i2 at = td2[r0 >> 1];
-            for (;;) {
-                // the next touched bucket's loads fly while this one is worked on
-                int pn = -1, rn = 0;
-                fb_f4 b0 = a0, b1 = a1;
-                fb_i2 bt = at;
-                if (dm) {
-                    pn = __builtin_ctzll(dm);
-                    dm &= dm - 1;
-                    rn = slot_of(pn);
-                    b0 = pts[rn]; b1 = pts[rn + 1];
-                    bt = td2[rn >> 1];
-                }
-                const float dx0 = a0[0] - x1, dy0 = a0[1] - y1, dz0 = a0[2] - z1;
-                const float dx1 = a1[0] - x1, dy1 = a1[1] - y1, dz1 = a1[2] - z1;
-                const float d0 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
-                const float d1 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
-                const int t0 = at[0], t1 = at[1];
-                const int n0 = min(f2i(d0), t0), n1 = min(f2i(d1), t1);
-                if (n0 != t0 || n1 != t1) td2[r0 >> 1] = fb_i2{n0, n1};
-                const int Tp = __builtin_amdgcn_readlane(Tv, p);
+            auto fetch = [&](Bucket &k) {                      // next touched bucket (dm != 0)
+                k.p = __builtin_ctzll(dm);
+                dm &= dm - 1;
+                k.r0 = slot_of(k.p);
+                k.c0 = pts[k.r0]; k.c1 = pts[k.r0 + 1];
+                k.t = td2[k.r0 >> 1];
+            };
+            auto work = [&](const Bucket &k) {
+                // both points per packed instruction; each component is an IEEE fp32 operation, so the
+                // result equals the scalar (dx*dx + dy*dy) + dz*dz bit for bit (as in fps.hip)
+                const f32x2 px = {k.c0[0], k.c1[0]}, py = {k.c0[1], k.c1[1]}, pz = {k.c0[2], k.c1[2]};
+                const f32x2 dx = px - x1, dy = py - y1, dz = pz - z1;
+                const f32x2 d = dx * dx + dy * dy + dz * dz;
+                const int t0 = k.t[0], t1 = k.t[1];
+                const int n0 = min(f2i(d[0]), t0), n1 = min(f2i(d[1]), t1);
+                if (n0 != t0 || n1 != t1) td2[k.r0 >> 1] = fb_i2{n0, n1};
+                const int Tp = __builtin_amdgcn_readlane(Tv, k.p);
                 if (__ballot((t0 == Tp && n0 != t0) || (t1 == Tp && n1 != t1))) {
                     // a holder of the bucket maximum was lowered: recompute (T, key)
                     const int v = max(n0, n1);
-                    const int k0 = f2i(a0[3]), k1 = f2i(a1[3]);
+                    const int k0 = f2i(k.c0[3]), k1 = f2i(k.c1[3]);
                     const int kk = n0 > n1 ? k0 : (n1 > n0 ? k1 : min(k0, k1));
                     const int wm = wave_max_i32(v);
                     const unsigned long long holders = __ballot(v == wm);
@@ -207,12 +192,23 @@ __global__ __launch_bounds__(NW * 64) void fb_sample_kernel(int n, int m, const 
                         wk = __builtin_amdgcn_readlane(kk, __builtin_ctzll(holders));
                     else
                         wk = fb_wave_min_i32(v == wm ? kk : 0x7fffffff);
-                    Tv = lane == p ? wm : Tv;
-                    Nk = lane == p ? ~wk : Nk;
+                    Tv = lane == k.p ? wm : Tv;
+                    Nk = lane == k.p ? ~wk : Nk;
                     changed = true;
                 }
-                if (pn < 0) break;
-                p = pn; r0 = rn; a0 = b0; a1 = b1; at = bt;
+            };
+            // two register sets in turn: the next touched bucket's loads fly while this one is worked on
+            Bucket ka, kb;
+            fetch(ka);
+            for (;;) {
+                const bool more_b = dm != 0;
+                if (more_b) fetch(kb);
+                work(ka);
+                if (!more_b) break;
+                const bool more_a = dm != 0;
+                if (more_a) fetch(ka);
+                work(kb);
+                if (!more_a) break;
             }
             if (changed) wave_best(wb_hi, wb_lo);
         }

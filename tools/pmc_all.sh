@@ -13,7 +13,7 @@ timeout -s KILL 90 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_writ
 python3 $R/tools/pmc_summary.py $O/trace_probe $O/pmc_fetch $O/pmc_write > $O/pmc_hot_kernels.json
 cp $O/trace_probe/*/*_kernel_stats.csv $O/probe_kernel_stats.csv
 timeout -s KILL 90 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -- python3 $R/tools/pmc_probe.py > /dev/null 2> $O/pmc_sq.err
-python3 $R/tools/pmc_counters.py $O/pmc_sq fps > $O/pmc_fps.json
+python3 $R/tools/pmc_counters.py $O/pmc_sq fps,fb_sample > $O/pmc_fps.json
 python3 $R/tools/pmc_counters.py $O/pmc_sq > $O/pmc_sq_all.json
 rm -rf $O/pmc_fetch $O/pmc_write $O/trace_probe $O/pmc_sq
 cat $O/pmc_fps.json

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel averages of the counters of one rocprofv3 --pmc CSV directory:
-  python tools/pmc_counters.py <pmc_dir> [kernel-name substring] > profiles/xxx.json
+  python tools/pmc_counters.py <pmc_dir> [kernel-name substring[,substring...]] > profiles/xxx.json
 """
 import csv
 import glob
@@ -11,13 +11,13 @@ import sys
 
 def main():
     d = sys.argv[1]
-    sub = sys.argv[2] if len(sys.argv) > 2 else ""
+    subs = (sys.argv[2] if len(sys.argv) > 2 else "").split(",")
     acc = {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 k = r["Kernel_Name"].replace("void ", "").replace("prcnn::", "").split("(")[0]
-                if sub not in k or "at::" in k:
+                if not any(sub in k for sub in subs) or "at::" in k:
                     continue
                 a = acc.setdefault(k, {}).setdefault(r["Counter_Name"], [0, 0.0])
                 a[0] += 1

@@ -82,6 +82,7 @@ def main():
         ops.sa_group_mlp_layer(new1, f1, new2, idx2, W99, *one(64))
         ops.query_ball_point_msg([0.1, 0.5], [16, 32], xyz, new1)
         ops.farthest_point_sample(4096, xyz)
+        ops.farthest_point_sample(4096, xyz, shared=True)
     torch.cuda.synchronize()
     import json
     print(json.dumps({"algorithmic_bytes_per_launch": work}))

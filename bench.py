@@ -80,6 +80,24 @@ def step(pcs, prop, store, precision, geo=None, centroids=None):
     return feats, detections(prop)
 
 
+_SPIN = {}
+
+
+def _spin(blocks, ms, mode, device):
+    """Probe only: tools/micro/libspin.so's resident kernel (one 256-thread workgroup per cloud for `ms`)."""
+    import ctypes
+    if not _SPIN:
+        lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "micro", "libspin.so"))
+        lib.spin_launch.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                    ctypes.c_void_p, ctypes.c_void_p]
+        _SPIN["lib"] = lib
+        _SPIN["ring"] = torch.randint(0, 1 << 20, (1 << 20,), dtype=torch.int32, device=device)
+        _SPIN["sink"] = torch.zeros(4, dtype=torch.int32, device=device)
+    rc = _SPIN["lib"].spin_launch(blocks, ms, mode, _SPIN["ring"].data_ptr(), _SPIN["ring"].numel(),
+                                  _SPIN["sink"].data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, rc
+
+
 def ahead_work(pcs_next, cent_next, group):
     """What runs AHEAD of (and beside) the feature phases: ONE strictly serial FPS chain over the
     clouds of the next `group` batches into `cent_next`."""
@@ -91,6 +109,9 @@ def ahead_work(pcs_next, cent_next, group):
     # CU to them (prcnn_farthest_point_sample_shared; PRCNN_BENCH_FPS_SHARED=0: the register-resident one).
     shared = os.environ.get("PRCNN_BENCH_FPS_SHARED", "1") != "0"
     probe = os.environ.get("PRCNN_BENCH_PROBE_NO_FPS")        # probes only (not valid bench lines)
+    if probe in ("70", "71", "72"):                           # level 1 replaced by a resident do-nothing / load / VALU kernel
+        _spin(xyz_next.shape[0], 4.0, int(probe) - 70, xyz_next.device)
+        probe = "2"
     if probe == "2":                                          # levels 2.. only (level 1 keeps its centroids)
         xs = [cent_next[0]] + stacks.sample_centroid_chain(cent_next[0], npoints[1:], shared=shared)[0]
     elif probe == "4":                                        # the fork / join and the copies alone: no sampling

@@ -1,0 +1,34 @@
+// Diagnostic only (bench.py PRCNN_BENCH_PROBE_NO_FPS=7x): a kernel with the small-footprint sampler's
+// shape (one 256-thread workgroup per cloud) that stays resident for a given time and does
+//   mode 0: nothing (s_sleep),  mode 1: a dependent chain of global loads,  mode 2: VALU work.
+// Bounded: every wave leaves after `ticks` of the 100 MHz clock or max_it iterations, whichever is first.
+#include <hip/hip_runtime.h>
+
+__global__ __launch_bounds__(256) void spin_kernel(long long ticks, int max_it, int mode, const int *__restrict__ ring,
+                                                   int ring_n, int *__restrict__ sink)
+{
+    const long long t0 = wall_clock64();
+    int pos = (blockIdx.x * 256 + threadIdx.x) % ring_n;
+    float acc = threadIdx.x;
+    for (int it = 0; it < max_it && wall_clock64() - t0 < ticks; ++it) {
+        if (mode == 0) {
+            __builtin_amdgcn_s_sleep(32);
+        } else if (mode == 1) {
+            pos = ring[pos] % ring_n;                 // dependent load: one L2 round trip per iteration
+            pos = pos < 0 ? 0 : pos;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 64; ++k) acc = acc * 1.0001f + 0.5f;
+        }
+    }
+    if (acc == -1.f || pos == -7) sink[0] = 1;        // never true: keeps the work alive
+}
+
+extern "C" int spin_launch(int blocks, double ms, int mode, const int *ring, int ring_n, int *sink, void *stream)
+{
+    if (blocks <= 0 || ring_n <= 0 || !ring || !sink) return -1;
+    const long long ticks = (long long)(ms * 1e5);    // 100 MHz
+    const int max_it = (int)(ms * 20000.0) + 1;
+    hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ticks, max_it, mode, ring, ring_n, sink);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

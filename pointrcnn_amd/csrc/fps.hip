@@ -20,6 +20,7 @@
 // Distances are non-negative floats (or the -1.0f "empty" sentinel), so all min / max /
 // compare run on the int bit patterns (order-preserving, no NaN canonicalisation code).
 #include "common.h"
+#include "fps_sort.h"
 #include <mutex>
 
 #ifndef PRCNN_FPS_PROBE
@@ -271,7 +272,7 @@ __global__ void gather_point_kernel(int n, int m, long long total, const float *
 
 // ---- pruned single-workgroup kernel (4096 < n <= 16384, long runs) ---------------------------
 // The plain kernel above is VALU-throughput bound: every iteration touches all n points.  Here
-// the cloud is first counting-sorted by grid cell inside the workgroup (14-bit anisotropic
+// the cloud is first counting-sorted by grid cell inside the workgroup (fps_sort.h: 14-bit anisotropic
 // Morton key, histogram in LDS) and cut into buckets of 128 consecutive sorted points; bucket
 // g belongs to wave g%16 as its point pair g/16 (2 points per lane), so neighbouring buckets
 // sit on different waves.  Each bucket keeps its bounding box, the maximum T of its running
@@ -282,8 +283,6 @@ __global__ void gather_point_kernel(int n, int m, long long total, const float *
 // The cached (T,K) of a bucket is recomputed only when a holder of T was lowered.  Winner =
 // (max value, smallest k mod 512, smallest k) on ORIGINAL indices, carried per point as a key,
 // so the result is independent of the sorted layout and bit-identical to fps_kernel.
-constexpr int FPR_KEY_BITS = 14;
-constexpr int FPR_CELLS = 1 << FPR_KEY_BITS;
 
 __device__ __forceinline__ int wave_min_i32_(int v) { return ~wave_max_i32(~v); }
 
@@ -297,12 +296,8 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(int n_cloud, int m,
 {
     constexpr int NT = NW * 64;
     constexpr int CAP = NT * 2 * P2;
-    __shared__ int hist[FPR_CELLS];
+    __shared__ FpsSortLds<NW> sort_lds;
     __shared__ unsigned short order[CAP];
-    __shared__ float red[NW][6];
-    __shared__ float sbox[4];
-    __shared__ int sbits[3];
-    __shared__ int wsum[NW];
     __shared__ unsigned long long slot[3];
     __shared__ unsigned long long bcast[2];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -328,101 +323,9 @@ __global__ __launch_bounds__(NW * 64) void fps_pruned_kernel(int n_cloud, int m,
     unsigned long long *cgran = COOP ? gran + (size_t)cloud * 2 * G : nullptr;
 
     // -- grid sort of the cloud (order inside a cell is arbitrary; nothing depends on it) --
-    {
-        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int i = tid; i < n; i += NT)
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const float v = data[i * 3 + d];
-                lo[d] = fminf(lo[d], v);
-                hi[d] = fmaxf(hi[d], v);
-            }
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                lo[d] = fminf(lo[d], __shfl_xor(lo[d], o));
-                hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], o));
-            }
-        if (lane == 0)
-            for (int d = 0; d < 3; ++d) { red[wave][d] = lo[d]; red[wave][3 + d] = hi[d]; }
-        for (int c = tid; c < FPR_CELLS; c += NT) hist[c] = 0;
-        if (tid < 3) slot[tid] = 0ull;
-        __syncthreads();
-        if (tid == 0) {
-            float ext[3], mx = 0.f;
-            for (int d = 0; d < 3; ++d) {
-                float l = red[0][d], h = red[0][3 + d];
-                for (int w = 1; w < NW; ++w) { l = fminf(l, red[w][d]); h = fmaxf(h, red[w][3 + d]); }
-                ext[d] = h - l;
-                if (!(ext[d] >= 0.f) || !(ext[d] < INFINITY)) ext[d] = 0.f;
-                mx = fmaxf(mx, ext[d]);
-                sbox[d] = l;
-            }
-            int bits[3] = {0, 0, 0};
-            float inv = 0.f;
-            // (an extent so small that mx / 1024 underflows to zero keeps every point in cell 0: the loop
-            // below would never end on cell == 0)
-            if (mx > 0.f && mx / 1024.f > 0.f) {
-                float cell = mx / 1024.f;
-                for (;;) {
-                    int tot = 0;
-                    for (int d = 0; d < 3; ++d) {
-                        const float cells = ext[d] / cell;
-                        int bt = 0;
-                        while (bt < 10 && (float)(1 << bt) < cells) ++bt;
-                        bits[d] = bt;
-                        tot += bt;
-                    }
-                    if (tot <= FPR_KEY_BITS) break;
-                    cell *= 2.f;
-                }
-                inv = 1.f / cell;
-            }
-            sbox[3] = inv;
-            for (int d = 0; d < 3; ++d) sbits[d] = bits[d];
-        }
-        __syncthreads();
-        const float b0 = sbox[0], b1 = sbox[1], b2 = sbox[2], inv = sbox[3];
-        const int t0 = sbits[0], t1 = sbits[1], t2 = sbits[2];
-        auto key_of = [&](int i) {
-            const float *p = data + i * 3;
-            const float f0 = (p[0] - b0) * inv, f1 = (p[1] - b1) * inv, f2 = (p[2] - b2) * inv;
-            const int q0 = f0 > 0.f ? (int)fminf(f0, (float)((1 << t0) - 1)) : 0;
-            const int q1 = f1 > 0.f ? (int)fminf(f1, (float)((1 << t1) - 1)) : 0;
-            const int q2 = f2 > 0.f ? (int)fminf(f2, (float)((1 << t2) - 1)) : 0;
-            int key = 0, pos = 0;
-            for (int lv = 0; lv < 10; ++lv) {
-                if (lv < t0) { key |= ((q0 >> lv) & 1) << pos; ++pos; }
-                if (lv < t1) { key |= ((q1 >> lv) & 1) << pos; ++pos; }
-                if (lv < t2) { key |= ((q2 >> lv) & 1) << pos; ++pos; }
-            }
-            return key;
-        };
-        for (int i = tid; i < n; i += NT) atomicAdd(&hist[key_of(i)], 1);
-        __syncthreads();
-        constexpr int PER = FPR_CELLS / NT;
-        int sum = 0;
-        for (int c = 0; c < PER; ++c) sum += hist[tid * PER + c];
-        int incl = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(incl, d);
-            if (lane >= d) incl += t;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int run = incl - sum;
-        for (int w = 0; w < wave; ++w) run += wsum[w];
-        for (int c = 0; c < PER; ++c) {
-            const int h = hist[tid * PER + c];
-            hist[tid * PER + c] = run;
-            run += h;
-        }
-        __syncthreads();
-        for (int i = tid; i < n; i += NT) order[atomicAdd(&hist[key_of(i)], 1)] = (unsigned short)i;
-        __syncthreads();
-    }
+    fps_grid_sort<NW>(data, n, sort_lds, order);
+    if (tid < 3) slot[tid] = 0ull;
+    __syncthreads();
 
     // -- this lane's points: sorted rank r = ((p*16 + wave) << 7) + u*64 + lane --
     f32x2 px[P2], py[P2], pz[P2];

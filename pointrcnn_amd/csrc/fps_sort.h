@@ -1,7 +1,7 @@
-// Grid sort of one cloud inside a workgroup (shared by the samplers that cut a cloud into buckets
-// of neighbouring points: fps_bucket.hip).  Counting sort by a 14-bit anisotropic Morton key over the
-// cloud's bounding box, histogram in LDS; the order inside a cell is arbitrary and nothing may
-// depend on it.
+// Grid sort of one cloud inside a workgroup, shared by the samplers that cut a cloud into buckets of
+// neighbouring points (fps_pruned_kernel in fps.hip, fb_sort_kernel in fps_bucket.hip).  Counting
+// sort by a 14-bit anisotropic Morton key over the cloud's bounding box, histogram in LDS; the
+// order inside a cell is arbitrary and nothing may depend on it.
 #pragma once
 #include "common.h"
 

@@ -413,6 +413,109 @@ class PipelinedSchedule:
         return self.units[0].outs[-1]
 
 
+def round_plan(k, nstreams, per_round=12, cap=5):
+    """K steps as rounds of ~per_round steps dealt to the step streams: a list of rounds, each a list of
+    per-stream unit sizes (batches; 0 = the stream sits the round out), every size <= cap, sizes inside a
+    round within one of each other, rounds within one step of each other.  Exactly K steps for any K."""
+    if k <= 0:
+        return []
+    rounds = max(1, (k + per_round // 2) // per_round)
+    while (k + rounds - 1) // rounds > cap * nstreams:
+        rounds += 1
+    plan = []
+    for r in range(rounds):
+        kr = k // rounds + (1 if r < k % rounds else 0)
+        plan.append([kr // nstreams + (1 if i < kr % nstreams else 0) for i in range(nstreams)])
+    return plan
+
+
+class RoundSchedule:
+    """The default pipelined schedule (end of round 2): S step streams and ONE sampling stream.  A round
+    runs the feature phases of up to S units (one linear HIP graph per step stream and unit size) beside
+    ONE sampling chain over the clouds of the whole next round -- a chain lasts the same for 64 or 240
+    clouds -- and ends with every step stream copying its share of the new centroids.  S + 1 lanes
+    instead of the 2 S of one forked graph per stream (PipelinedSchedule), so three step streams fit the
+    hardware queues: 13.9 k scenes/s against 12.2 k.  Needs >= S + 2 hardware queues
+    (bench.py sets 8).  Every batch still gets one complete sampling pass and one complete feature
+    phase; a chain always samples S x cap batches, so rounds with smaller units sample some twice."""
+
+    def __init__(self, device, nstreams, steps, warmup, pcs, prop, store, precision, per_round=12, cap=5):
+        S = nstreams
+        self.S = S
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(S)]
+        self.sampler = torch.cuda.Stream(device=device)
+        self.per_round, self.capmax = per_round, cap
+        plans = round_plan(steps, S, per_round, cap) + round_plan(warmup, S, per_round, cap)
+        self.cap = max([g for rnd in plans for g in rnd] + [1])
+        self.group = self.cap                                    # reported as batches_per_replay
+        self.b = pcs.shape[0]
+        self.pcs, self.prop, self.store, self.precision = pcs, prop, store, precision
+        npoints = [lv[0] for lv in stacks.RPN_SA]
+        with torch.cuda.stream(self.sampler):
+            xyz_all = pcs[:, :, 0:3].contiguous().repeat(S * self.cap, 1, 1)
+            xs, _ = stacks.sample_centroid_chain(xyz_all, npoints)
+            self.cent_next = [x.clone() for x in xs]
+            ahead_work(pcs, self.cent_next, S * self.cap)        # warm-up of the chain as it is captured
+        torch.cuda.synchronize()
+        rows = self.cap * self.b
+        self.cent_cur = [[c[s * rows:(s + 1) * rows].clone() for c in self.cent_next] for s in range(S)]
+        self.units = {}                                          # (stream, size) -> (graph, outs)
+        for rnd in plans:
+            for s_, g in enumerate(rnd):
+                if g and (s_, g) not in self.units:
+                    self.units[(s_, g)] = self._capture(s_, g)
+        self.g_chain = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_chain, stream=self.sampler):
+            ahead_work(pcs, self.cent_next, S * self.cap)
+        self.chain_done = torch.cuda.Event()
+        self.copied = [torch.cuda.Event() for _ in self.streams]
+        self.started = False
+        self.last = None
+
+    def _capture(self, s_, g):
+        st = self.streams[s_]
+        with torch.cuda.stream(st):
+            feature_work(self.pcs, self.prop, self.store, self.precision, self.cent_cur[s_], g)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            outs = feature_work(self.pcs, self.prop, self.store, self.precision, self.cent_cur[s_], g)
+        return graph, outs
+
+    def run(self, k, ring):
+        rows = self.cap * self.b
+        pos = 0
+        for rnd in round_plan(k, self.S, self.per_round, self.capmax):
+            if self.started:
+                for ev in self.copied:                           # cent_next is free once every stream has taken its share
+                    self.sampler.wait_event(ev)
+            with torch.cuda.stream(self.sampler):
+                self.g_chain.replay()
+                self.chain_done.record(self.sampler)
+            for s_, g in enumerate(rnd):
+                st = self.streams[s_]
+                with torch.cuda.stream(st):
+                    if g:
+                        if (s_, g) not in self.units:            # (a size the constructor was not told of: untimed use only)
+                            self.units[(s_, g)] = self._capture(s_, g)
+                        graph, outs = self.units[(s_, g)]
+                        graph.replay()
+                        for _, rec in outs:
+                            ring[pos].copy_(rec)                 # the unit rewrites its own records on the next replay
+                            pos += 1
+                        if s_ == 0:
+                            self.last = outs[-1]
+                    st.wait_event(self.chain_done)
+                    for dst, src in zip(self.cent_cur[s_], self.cent_next):
+                        dst.copy_(src[s_ * rows:(s_ + 1) * rows])
+                    self.copied[s_].record(st)
+            self.started = True
+        return pos
+
+    def last_outputs(self):
+        return self.last
+
+
 class SimpleSchedule:
     """One batch per unit, FPS inside the batch's own step (--no-pipeline / --no-graph / --geo-stream)."""
 
@@ -541,7 +644,8 @@ def main():
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32")
     # concurrent batches in flight; each has a companion stream for the next batch's FPS chain,
     # and 2+2 streams = HIP's 4 hardware queues (measured: 3+3 aliases queues and loses 20 %)
-    ap.add_argument("--streams", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=0,
+                    help="step streams (0 = 3 for the round schedule, 2 for the forked-graph schedule)")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -577,10 +681,15 @@ def main():
     # run without a group drops to 7.6k).  DESIGN.md 5 has the table.  So: 8 queues when a process group
     # will be formed, the default otherwise (PRCNN_HW_QUEUES overrides); the variable is read when HIP
     # initialises (first HIP call, below).
+    # The round schedule (default; RoundSchedule) runs S + 1 = 4 lanes of linear graphs and wants a queue per lane
+    # plus the null stream's: 5, 6 and 8 queues measure alike (13.9 k scenes/s), 4 lose a fifth (10.8 k).
     grouped = int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("PRCNN_DIST_FORCE") == "1"
+    pipelined = not (args.no_graph or args.no_pipeline or args.geo_stream)
+    rounds = (pipelined and os.environ.get("PRCNN_BENCH_ROUNDS", "1") != "0" and args.fps_group <= 0
+              and os.environ.get("PRCNN_BENCH_PROBE_NO_FPS") not in ("1", "6") and os.environ.get("PRCNN_BENCH_TAP") != "1")
     if os.environ.get("PRCNN_HW_QUEUES"):                       # explicit choice for this bench
         os.environ["GPU_MAX_HW_QUEUES"] = os.environ["PRCNN_HW_QUEUES"]
-    elif grouped and os.environ.get("GPU_MAX_HW_QUEUES", "4") == "4":   # unset, or exported at HIP's own default
+    elif (grouped or rounds) and os.environ.get("GPU_MAX_HW_QUEUES", "4") == "4":   # unset, or exported at HIP's own default
         os.environ["GPU_MAX_HW_QUEUES"] = "8"
     rank, world, local = pdist.init_from_env("cuda")
     if world != args.gpus and world > 1:
@@ -591,8 +700,7 @@ def main():
     store = PU.ParamStore(seed=7, device=device)
     # PRCNN_BENCH_INPUT_RANK: run rank r's scenes in a one-process run (tests compare them with the N > 1 job's)
     pcs, prop = make_inputs(int(os.environ.get("PRCNN_BENCH_INPUT_RANK", rank)), device, args.batch)
-    nstreams = max(1, args.streams)
-    pipelined = not (args.no_graph or args.no_pipeline or args.geo_stream)
+    nstreams = args.streams if args.streams > 0 else (3 if rounds else 2)
     group = max(1, args.fps_group) if pipelined else 1
     if pipelined and args.fps_group <= 0:
         even = [g for g in (4, 5, 6, 3, 8) if args.steps % (g * nstreams) == 0]
@@ -600,6 +708,10 @@ def main():
     ring = torch.zeros((max(args.steps, args.warmup, 1), args.batch, pdist.RECORD_LEN), dtype=torch.float32, device=device)
 
     def make_schedule():
+        if rounds:
+            return RoundSchedule(device, nstreams, args.steps, args.warmup, pcs, prop, store, precision,
+                                 per_round=int(os.environ.get("PRCNN_BENCH_ROUND_STEPS", "12")),
+                                 cap=int(os.environ.get("PRCNN_BENCH_ROUND_CAP", "5")))
         if pipelined:
             return PipelinedSchedule(device, nstreams, group, True, bool(args.steps % group or args.warmup % group),
                                      pcs, prop, store, precision)
@@ -691,6 +803,9 @@ def main():
         ops.set_timer(prev)
     torch.cuda.synchronize()
     n_streams_used = len(sched.streams)
+    if rounds:
+        group = sched.group
+        round_sizes = round_plan(args.steps, nstreams, sched.per_round, sched.capmax)
     hip_graph = not args.no_graph
     del sched, feats_replay, rec_replay, feats_eager, rec_eager
 
@@ -801,7 +916,10 @@ def main():
                                                if os.environ.get("PRCNN_BENCH_FPS_SHARED", "1") != "0"
                                                else "register-resident (one CU per cloud)") if pipelined else "register-resident (one CU per cloud)"),
                        "duplicate_free_groups": bool(PU.SA_DEDUP), "ball_fill": ball_fill(pcs),
-                       "batches_per_replay": group, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "eager_remainder_steps": (args.steps % group) if pipelined else 0,
+                       "batches_per_replay": group, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "eager_remainder_steps": (args.steps % group) if (pipelined and not rounds) else 0,
+                       "schedule": ("rounds: %d step streams (one linear graph per unit) + 1 sampling stream (one chain per round); "
+                                    "unit sizes per round %s" % (nstreams, round_sizes) if rounds else
+                                    ("one forked graph per step stream" if pipelined else "one batch per unit")),
                        "replay_equals_eager": replay_ok, "replay_diff": replay_diff,
                        "kernel_timing": "HIP events around every launch in an eager, single-stream instrumented "
                                         "pass of the same steps after the timed region",

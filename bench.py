@@ -414,18 +414,16 @@ class PipelinedSchedule:
 
 
 def round_plan(k, nstreams, per_round=12, cap=5):
-    """K steps as rounds of ~per_round steps dealt to the step streams: a list of rounds, each a list of
-    per-stream unit sizes (batches; 0 = the stream sits the round out), every size <= cap, sizes inside a
-    round within one of each other, rounds within one step of each other.  Exactly K steps for any K."""
-    if k <= 0:
-        return []
-    rounds = max(1, (k + per_round // 2) // per_round)
-    while (k + rounds - 1) // rounds > cap * nstreams:
-        rounds += 1
+    """K steps as rounds dealt to the step streams: a list of rounds, each a list of per-stream unit sizes
+    (batches; 0 = the stream sits the round out).  Full rounds of per_round steps (equal units: a stream
+    that runs a batch more than the others runs it alone) and ONE last round with what is left, its sizes
+    within one of each other; every size <= cap.  Exactly K steps for any K."""
+    per_round = max(nstreams, min(per_round, cap * nstreams))
     plan = []
-    for r in range(rounds):
-        kr = k // rounds + (1 if r < k % rounds else 0)
+    while k > 0:
+        kr = min(k, per_round)
         plan.append([kr // nstreams + (1 if i < kr % nstreams else 0) for i in range(nstreams)])
+        k -= kr
     return plan
 
 

@@ -413,7 +413,7 @@ class PipelinedSchedule:
         return self.units[0].outs[-1]
 
 
-def round_plan(k, nstreams, per_round=12, cap=5):
+def round_plan(k, nstreams, per_round=12, cap=4):
     """K steps as rounds dealt to the step streams: a list of rounds, each a list of per-stream unit sizes
     (batches; 0 = the stream sits the round out).  Full rounds of per_round steps (equal units: a stream
     that runs a batch more than the others runs it alone) and ONE last round with what is left, its sizes
@@ -437,7 +437,7 @@ class RoundSchedule:
     (bench.py sets 8).  Every batch still gets one complete sampling pass and one complete feature
     phase; a chain always samples S x cap batches, so rounds with smaller units sample some twice."""
 
-    def __init__(self, device, nstreams, steps, warmup, pcs, prop, store, precision, per_round=12, cap=5):
+    def __init__(self, device, nstreams, steps, warmup, pcs, prop, store, precision, per_round=12, cap=4):
         S = nstreams
         self.S = S
         self.streams = [torch.cuda.Stream(device=device) for _ in range(S)]
@@ -709,7 +709,7 @@ def main():
         if rounds:
             return RoundSchedule(device, nstreams, args.steps, args.warmup, pcs, prop, store, precision,
                                  per_round=int(os.environ.get("PRCNN_BENCH_ROUND_STEPS", "12")),
-                                 cap=int(os.environ.get("PRCNN_BENCH_ROUND_CAP", "5")))
+                                 cap=int(os.environ.get("PRCNN_BENCH_ROUND_CAP", "4")))
         if pipelined:
             return PipelinedSchedule(device, nstreams, group, True, bool(args.steps % group or args.warmup % group),
                                      pcs, prop, store, precision)

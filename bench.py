@@ -13,12 +13,15 @@ per-scene detection records produced in the timed region, issued at its closing 
 One "step" = one such batch per rank (weak scaling).  Inputs are resident in HBM before
 the timed region; nothing is allocated inside it.
 
-Schedule (PipelinedSchedule / Unit): one HIP graph per step stream holding the feature
-phases of `group` batches and, on a forked branch, ONE farthest-point-sampling chain
-over the clouds of the NEXT `group` batches (software pipelining: every batch still
-gets one complete FPS pass and one complete feature phase); K mod group remainder steps
-run eagerly, so exactly K steps are timed for any K.  After the timed region a replay's
-features and records are compared bit for bit with an eager, un-pipelined step.
+Schedule (RoundSchedule, the default): three step streams, each replaying one linear HIP
+graph per unit of up to 4 batches (the feature phases), beside ONE sampling stream whose
+single farthest-point-sampling chain per round samples the clouds of the whole NEXT
+round (software pipelining: every batch still gets a complete FPS pass and a complete
+feature phase); `round_plan` deals any K into rounds, so exactly K steps are timed and
+nothing is issued eagerly.  After the timed region a replay's features and records are
+compared bit for bit with an eager, un-pipelined step.  PRCNN_BENCH_ROUNDS=0 or
+--fps-group N: the earlier schedule (PipelinedSchedule / Unit: one forked graph per step
+stream, features + that unit's own chain; K mod group remainder steps eager).
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant roofline-bound launch;
 durations from HIP events in an eager single-stream pass, HBM traffic from the committed
@@ -640,8 +643,8 @@ def main():
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32")
-    # concurrent batches in flight; each has a companion stream for the next batch's FPS chain,
-    # and 2+2 streams = HIP's 4 hardware queues (measured: 3+3 aliases queues and loses 20 %)
+    # concurrent units in flight (round schedule: + 1 sampling stream; forked-graph schedule: each step stream has a
+    # companion stream for its chain, and 2+2 streams = HIP's 4 hardware queues -- 3+3 aliases queues and loses 20 %)
     ap.add_argument("--streams", type=int, default=0,
                     help="step streams (0 = 3 for the round schedule, 2 for the forked-graph schedule)")
     ap.add_argument("--batch", type=int, default=BATCH)

@@ -95,7 +95,7 @@ def _spin(blocks, ms, mode, device):
                                     ctypes.c_void_p, ctypes.c_void_p]
         _SPIN["lib"] = lib
         _SPIN["ring"] = torch.randint(0, 1 << 20, (1 << 20,), dtype=torch.int32, device=device)
-        _SPIN["sink"] = torch.zeros(4, dtype=torch.int32, device=device)
+        _SPIN["sink"] = torch.zeros(2 * (128 + 1024 * 512), dtype=torch.int32, device=device)
     rc = _SPIN["lib"].spin_launch(blocks, ms, mode, _SPIN["ring"].data_ptr(), _SPIN["ring"].numel(),
                                   _SPIN["sink"].data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert rc == 0, rc
@@ -112,7 +112,7 @@ def ahead_work(pcs_next, cent_next, group):
     # CU to them (prcnn_farthest_point_sample_shared; PRCNN_BENCH_FPS_SHARED=0: the register-resident one).
     shared = os.environ.get("PRCNN_BENCH_FPS_SHARED", "1") != "0"
     probe = os.environ.get("PRCNN_BENCH_PROBE_NO_FPS")        # probes only (not valid bench lines)
-    if probe in ("70", "71", "72"):                           # level 1 replaced by a resident do-nothing / load / VALU kernel
+    if probe in ("70", "71", "72", "73"):                     # level 1 replaced by a resident do-nothing / load / VALU / load+store kernel
         _spin(xyz_next.shape[0], 4.0, int(probe) - 70, xyz_next.device)
         probe = "2"
     if probe == "2":                                          # levels 2.. only (level 1 keeps its centroids)

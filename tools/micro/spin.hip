@@ -1,6 +1,7 @@
 // Diagnostic only (bench.py PRCNN_BENCH_PROBE_NO_FPS=7x): a kernel with the small-footprint sampler's
 // shape (one 256-thread workgroup per cloud) that stays resident for a given time and does
-//   mode 0: nothing (s_sleep),  mode 1: a dependent chain of global loads,  mode 2: VALU work.
+//   mode 0: nothing (s_sleep),  mode 1: a dependent chain of global loads,  mode 2: VALU work,
+//   mode 3: mode 1 plus one 8-byte global store per lane and iteration (sink must hold 128 + blocks * 512 long longs).
 // Bounded: every wave leaves after `ticks` of the 100 MHz clock or max_it iterations, whichever is first.
 #include <hip/hip_runtime.h>
 
@@ -16,6 +17,10 @@ __global__ __launch_bounds__(256) void spin_kernel(long long ticks, int max_it, 
         } else if (mode == 1) {
             pos = ring[pos] % ring_n;                 // dependent load: one L2 round trip per iteration
             pos = pos < 0 ? 0 : pos;
+        } else if (mode == 3) {
+            pos = ring[pos] % ring_n;                 // the load chain of mode 1 + one 8-byte store per lane (dirty L2 lines)
+            pos = pos < 0 ? 0 : pos;
+            reinterpret_cast<long long *>(sink)[64 + (size_t)(blockIdx.x * 256 + threadIdx.x) * 2 + (it & 1)] = pos;
         } else {
 #pragma unroll
             for (int k = 0; k < 64; ++k) acc = acc * 1.0001f + 0.5f;

@@ -112,10 +112,10 @@ def ahead_work(pcs_next, cent_next, group):
     # CU to them (prcnn_farthest_point_sample_shared; PRCNN_BENCH_FPS_SHARED=0: the register-resident one).
     shared = os.environ.get("PRCNN_BENCH_FPS_SHARED", "1") != "0"
     probe = os.environ.get("PRCNN_BENCH_PROBE_NO_FPS")        # probes only (not valid bench lines)
-    if probe in ("70", "71", "72", "73", "74"):               # level 1 replaced by a resident do-nothing / load / VALU / load+store kernel
+    if probe in ("70", "71", "72", "73", "74", "75"):               # level 1 replaced by a resident do-nothing / load / VALU / load+store kernel
         if probe == "74":                                     # ... preceded by the shared sampler's sort launch alone (npoint = 1)
             ops.farthest_point_sample(1, xyz_next, shared=True)
-        _spin(xyz_next.shape[0], 4.0, 0 if probe == "74" else int(probe) - 70, xyz_next.device)
+        _spin(xyz_next.shape[0], 4.0, {"74": 0, "75": 4}.get(probe, int(probe) - 70), xyz_next.device)
         probe = "2"
     if probe == "2":                                          # levels 2.. only (level 1 keeps its centroids)
         xs = [cent_next[0]] + stacks.sample_centroid_chain(cent_next[0], npoints[1:], shared=shared)[0]

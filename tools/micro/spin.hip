@@ -1,7 +1,8 @@
 // Diagnostic only (bench.py PRCNN_BENCH_PROBE_NO_FPS=7x): a kernel with the small-footprint sampler's
 // shape (one 256-thread workgroup per cloud) that stays resident for a given time and does
 //   mode 0: nothing (s_sleep),  mode 1: a dependent chain of global loads,  mode 2: VALU work,
-//   mode 3: mode 1 plus one 8-byte global store per lane and iteration (sink must hold 128 + blocks * 512 long longs).
+//   mode 3: mode 1 plus one 8-byte global store per lane and iteration (sink must hold 128 + blocks * 512 long longs),
+//   mode 4: the sampler's per-iteration LDS atomic + workgroup barrier + LDS read, nothing else.
 // Bounded: every wave leaves after `ticks` of the 100 MHz clock or max_it iterations, whichever is first.
 #include <hip/hip_runtime.h>
 
@@ -17,6 +18,14 @@ __global__ __launch_bounds__(256) void spin_kernel(long long ticks, int max_it, 
         } else if (mode == 1) {
             pos = ring[pos] % ring_n;                 // dependent load: one L2 round trip per iteration
             pos = pos < 0 ? 0 : pos;
+        } else if (mode == 4) {
+            // the sampler's synchronisation skeleton: one LDS atomic per wave, a workgroup barrier, an LDS read, ~1 us apart
+            __shared__ unsigned long long slot[3];
+            if ((threadIdx.x & 63) == 0) atomicMax(&slot[it % 3], (unsigned long long)(it + threadIdx.x));
+            __syncthreads();
+            pos = (int)(slot[it % 3] & 1023);
+            if (threadIdx.x == 0) slot[(it + 2) % 3] = 0ull;
+            __builtin_amdgcn_s_sleep(24);
         } else if (mode == 3) {
             pos = ring[pos] % ring_n;                 // the load chain of mode 1 + one 8-byte store per lane (dirty L2 lines)
             pos = pos < 0 ? 0 : pos;
